@@ -1,0 +1,208 @@
+/*
+ * ongym.h — C ABI of the MI355X-native batched QRMSA environment (libongym_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of LEA-UFPA/optical-networking-gym: the per-request loop of
+ * optical_networking_gym/envs/qrmsa.pyx (first-fit policy + step + traffic/departure bookkeeping) with the GN model of
+ * optical_networking_gym/core/osnr.pyx.  The reference has no C interface of its own (its Cython modules only export
+ * the CPython module init), so each entry point below names the reference Python/Cython interface it replaces.
+ * Plain pointers and sizes only; no torch / numpy types.  Host code stays Python (ctypes), see INTEGRATION.md.
+ *
+ * Ownership : the library owns all device state; callers own every buffer they pass in.  Input tables given to
+ *             ongym_create are copied.  Output buffers are host pointers, or device pointers when cfg.io_device = 1
+ *             (e.g. torch.Tensor.data_ptr() of a PyTorch-ROCm tensor on the same device).
+ * Errors    : every call returns 0 on success, <0 on error (ONGYM_E_*); ongym_last_error() gives text. Nothing throws.
+ *             The reference's ValueError on a QoT-infeasible action (qrmsa.pyx:925-929) is the per-replica
+ *             ONGYM_F_QOT_ERROR flag of ongym_step_rec.flags (the Python shim re-raises it in single-env mode).
+ * Threading : one ongym_env = one HIP device + one HIP stream; not thread-safe; launches are asynchronous on that
+ *             stream, results are complete after ongym_sync() (calls that copy to host buffers sync themselves).
+ * Multi-GPU : one process per GPU, one ongym_env each; replicas are independent so there is no data-path collective.
+ */
+#ifndef ONGYM_H
+#define ONGYM_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ONGYM_ABI_VERSION 1
+
+enum {
+    ONGYM_OK = 0,
+    ONGYM_E_ARG = -1,      /* bad argument / inconsistent tables */
+    ONGYM_E_HIP = -2,      /* HIP runtime error (no device, launch failure, ...) */
+    ONGYM_E_STATE = -3,    /* call not valid in the current state (e.g. no request source set) */
+    ONGYM_E_CAPACITY = -4, /* a replica overflowed its service table (cfg.capacity too small) */
+    ONGYM_E_LIMIT = -5     /* configuration exceeds a compile-time limit of the kernels */
+};
+
+/* policies fused on device; replaces optical_networking_gym/heuristics/heuristics.py:923-966 */
+enum { ONGYM_POLICY_FIRST_FIT = 0 };
+
+/* ongym_step_rec.flags */
+enum {
+    ONGYM_F_BLOCKED_RESOURCES = 1, /* 2nd element of the heuristic's return tuple, heuristics.py:966 */
+    ONGYM_F_BLOCKED_OSNR = 2,      /* 3rd element */
+    ONGYM_F_QOT_ERROR = 4,         /* action decoded to free slots whose GSNR < threshold+margin: qrmsa.pyx:925-929 */
+    ONGYM_F_OVERFLOW = 8,          /* service table full: request was rejected artificially, results invalid */
+    ONGYM_F_NO_REQUEST = 16        /* replay trace exhausted: step was a no-op */
+};
+
+/*
+ * Static description of the network + traffic.  Replaces the arguments of QRMSAEnv.__init__ (qrmsa.pyx:206-237) and
+ * the data that optical_networking_gym/topology.pyx:244-369 (get_topology) attaches to the graph, flattened:
+ *   pair_paths[(src*n_nodes+dst)*k_paths + k] = path id or -1      (k_shortest_paths[src,dst][k], qrmsa.pyx:277)
+ *   path_links[p*max_hops + h], h < path_hops[p]                    (Path.links, topology.pyx:72-95; link "index")
+ *   link_*[e]                                                       (Link.spans: all spans of a link are equal,
+ *                                                                    topology.pyx:288-299; alpha in 1/m, nf linear,
+ *                                                                    Span, topology.pyx:11-34)
+ *   mod_se / mod_min_osnr [m]                                       (Modulation, topology.pyx:53-70), m ascending
+ */
+typedef struct ongym_config {
+    int32_t struct_size; /* = sizeof(ongym_config) */
+    int32_t abi_version; /* = ONGYM_ABI_VERSION */
+    int32_t n_nodes, n_links, n_paths, k_paths, max_hops, n_mods, n_slots;
+    int32_t batch;          /* number of independent replicas B */
+    int32_t capacity;       /* max simultaneously running services per replica (multiple of 64) */
+    int32_t episode_length; /* qrmsa.pyx:210; an episode is episode_length-1 steps */
+    int32_t auto_reset;     /* 1: a replica that terminates is reset inside the same launch (graph_load.py:157-158) */
+    int32_t bit_rate_mode;  /* 0 = "discrete" (bit_rates/bit_rate_cum), 1 = "continuous" (randint(lo,hi)) */
+    int32_t n_bit_rates;
+    int32_t bit_rate_lo, bit_rate_hi;
+    int32_t device;         /* HIP device ordinal */
+    int32_t io_device;      /* 1: in/out buffers of step/set_requests calls are device pointers */
+    int32_t reserved0;
+    double frequency_start;       /* Hz,  qrmsa.pyx:221 */
+    double slot_bandwidth;        /* Hz,  qrmsa.pyx:222 */
+    double channel_width;         /* GHz, qrmsa.pyx:228 (get_number_slots, qrmsa.pyx:1198-1205) */
+    double launch_power_w;        /* 10**((dBm-30)/10), qrmsa.pyx:288 */
+    double margin;                /* dB, qrmsa.pyx:223 */
+    double load;                  /* Erlang, qrmsa.pyx:211 */
+    double mean_holding_time;     /* s, qrmsa.pyx:212 */
+    const int32_t *pair_paths;    /* [n_nodes*n_nodes*k_paths] */
+    const int32_t *path_hops;     /* [n_paths] */
+    const int32_t *path_links;    /* [n_paths*max_hops] */
+    const int32_t *link_nspans;   /* [n_links] */
+    const double *link_span_km;   /* [n_links] */
+    const double *link_alpha;     /* [n_links] 1/m */
+    const double *link_nf;        /* [n_links] linear */
+    const int32_t *mod_se;        /* [n_mods] spectral efficiency (1..6) */
+    const double *mod_min_osnr;   /* [n_mods] dB */
+    const double *bit_rates;      /* [n_bit_rates] Gb/s */
+    const double *bit_rate_cum;   /* [n_bit_rates] cumulative probabilities, last = 1 */
+    const double *node_cum;       /* [n_nodes] cumulative node request probabilities, last = 1 (qrmsa.pyx:278-286) */
+    /* optional per-replica overrides (NULL = use the scalar above): the JOCN sweeps over launch power / load / margin
+     * (graph_launch_power.py, graph_load.py, graph_margin.py) become a batch dimension */
+    const double *replica_launch_power_w; /* [batch] */
+    const double *replica_load;           /* [batch] */
+    const double *replica_margin;         /* [batch] */
+} ongym_config;
+
+/* One service request; replaces the fields drawn in QRMSAEnv._next_service (qrmsa.pyx:1079-1101). */
+typedef struct ongym_request {
+    float arrival_time; /* absolute, already rounded to float32 like the reference's `cdef float at` */
+    float holding_time;
+    float bit_rate;
+    int16_t source;     /* node index */
+    int16_t destination;
+} ongym_request;
+
+/* Per-replica result of one step; replaces the (obs, reward, terminated, truncated, info) tuple of QRMSAEnv.step
+ * (qrmsa.pyx:838-1065) for gen_observation=False, plus what the heuristic returned. 56 bytes. */
+typedef struct ongym_step_rec {
+    int32_t action;      /* action index applied (p*M*S + (max_mod-m)*S + slot, reject = k*M*S; heuristics.py:36-54) */
+    int16_t route;       /* info["chosen_path_index"], -1 on reject */
+    int16_t modulation;  /* absolute modulation index, -1 on reject */
+    int16_t slot;        /* info["chosen_slot"], -1 on reject */
+    int16_t nslots;
+    uint8_t accepted;
+    uint8_t terminated;
+    uint8_t retry;       /* 1: slots were not free, request stays current (qrmsa.pyx:886-897) */
+    uint8_t flags;       /* ONGYM_F_* */
+    int32_t active;      /* running services after the step (len(topology.graph["running_services"])) */
+    double osnr, ase, nli; /* dB, of the accepted service (info["osnr"]); 0 on reject */
+    double reward;
+} ongym_step_rec;
+
+/* A running service as seen by the compatibility view (Service, qrmsa.pyx:29-53). */
+typedef struct ongym_service {
+    int32_t path_id;
+    int16_t slot, nslots;
+    int16_t modulation;
+    int16_t reserved;
+    float release_time; /* float32(arrival+holding), the heap key after rounding (qrmsa.pyx:1114-1115,1329) */
+} ongym_service;
+
+/* Counters behind the info dict (qrmsa.pyx:996-1060) and the JOCN per-episode CSV row (graph_load.py:169-186). */
+typedef struct ongym_stats {
+    int64_t services_processed, services_accepted;                 /* never reset (quirk Q3) */
+    int64_t episode_services_processed, episode_services_accepted; /* current episode */
+    double bit_rate_requested, bit_rate_provisioned;               /* reset by reset(), qrmsa.pyx:466-467 */
+    double episode_bit_rate_requested, episode_bit_rate_provisioned;
+    int64_t rejected;                                              /* bl_reject of the current episode */
+    int64_t episode_modulation_hist[8];
+    double episode_osnr_sum;                                       /* sum of Service.OSNR over the episode's services */
+    int64_t episodes_completed;
+    /* snapshot taken at the last terminal step (what graph_load.py writes per episode) */
+    int64_t last_episode_processed, last_episode_accepted, last_rejected;
+    double last_service_blocking_rate, last_episode_service_blocking_rate;
+    double last_bit_rate_blocking_rate, last_episode_bit_rate_blocking_rate;
+    int64_t last_modulation_hist[8];
+    double last_mean_gsnr;
+    /* totals over all completed steps since create (for throughput accounting and the RCCL stats reduction) */
+    int64_t total_steps, total_accepted, total_gn_evals, total_interferer_terms;
+    double current_time;
+    int32_t active, flags;
+} ongym_stats;
+
+typedef struct ongym_env ongym_env;
+
+/* QRMSAEnv.__init__ (qrmsa.pyx:206-425) for B replicas; does NOT generate the first request: call
+ * ongym_seed or ongym_set_requests, then ongym_reset. */
+int ongym_create(const ongym_config *cfg, ongym_env **out);
+void ongym_destroy(ongym_env *env);
+
+/* Request source A — device generator: replica r draws from the counter-based stream (seed, r) defined in
+ * ongym_traffic.h.  Stands in for `self.rng = random.Random()` (qrmsa.pyx:241; unseeded in the reference, quirk Q2). */
+int ongym_seed(ongym_env *env, uint64_t seed);
+/* Request source B — trace replay: reqs[r*n_per_replica + i] is the i-th request replica r will draw.
+ * Used for parity against captured reference traces (each _next_service call consumes one entry). */
+int ongym_set_requests(ongym_env *env, const ongym_request *reqs, int64_t n_per_replica);
+
+/* QRMSAEnv.reset (qrmsa.pyx:427-504) on the replicas with mask[r] != 0 (NULL = all). */
+int ongym_reset(ongym_env *env, const uint8_t *mask);
+
+/* nsteps iterations of `action,_,_ = heuristic(env); env.step(action)` (graph_load.py:161-163) fused on device.
+ * out: [nsteps][batch] records or NULL. */
+int ongym_step_policy(ongym_env *env, int32_t policy, int32_t nsteps, ongym_step_rec *out);
+/* QRMSAEnv.step(action) (qrmsa.pyx:838-1065) with caller-supplied actions[batch]. out: [batch] or NULL. */
+int ongym_step_actions(ongym_env *env, const int32_t *actions, ongym_step_rec *out);
+/* The heuristic alone, without stepping: actions[batch], flags[batch] (ONGYM_F_BLOCKED_*) (heuristics.py:923-966). */
+int ongym_policy_actions(ongym_env *env, int32_t policy, int32_t *actions, uint8_t *flags);
+
+/* Plugin-API queries on one replica (host buffers always): */
+/* QRMSAEnv.get_available_slots(path) (qrmsa.pyx:1482-1512): out[n_slots], 1 = free on every link of the path */
+int ongym_query_available(ongym_env *env, int32_t replica, int32_t path_id, int32_t *out);
+/* calculate_osnr(env, service) (core/osnr.pyx:21-142) for a candidate (path, slot, nslots): out = gsnr, ase, nli dB */
+int ongym_query_gsnr(ongym_env *env, int32_t replica, int32_t path_id, int32_t slot, int32_t nslots, double out[3]);
+/* topology.graph["available_slots"] (qrmsa.pyx:306-309): out[n_links*n_slots] */
+int ongym_query_grid(ongym_env *env, int32_t replica, int32_t *out);
+/* topology.graph["running_services"]: out[capacity], *n = count */
+int ongym_query_services(ongym_env *env, int32_t replica, ongym_service *out, int32_t *n);
+/* QRMSAEnv.current_service */
+int ongym_query_request(ongym_env *env, int32_t replica, ongym_request *out);
+
+/* per-replica counters: out[batch] (host buffer) */
+int ongym_stats_get(ongym_env *env, ongym_stats *out);
+
+int ongym_sync(ongym_env *env);
+/* Device time (ms, HIP events on the env's stream) of the most recent step launch; <0 if none. */
+double ongym_last_kernel_ms(ongym_env *env);
+const char *ongym_last_error(ongym_env *env);
+/* sizes the host side needs to allocate buffers / check the build */
+int32_t ongym_abi_version(void);
+int32_t ongym_sizeof(int32_t what); /* 0 config, 1 request, 2 step_rec, 3 service, 4 stats */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ONGYM_H */

@@ -1,0 +1,577 @@
+/*
+ * ongym_oracle.c — CPU restatement of the reference's QRMSA per-request hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the *checker* for the HIP path: only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it.  The product (libongym_hip.so and the Python package) never imports,
+ * links or executes anything under oracle/.
+ *
+ * Parity status: PINNED.  The reference ships no golden vectors for this path, so the oracle is pinned
+ * against outputs of the reference itself, generated in the build container by tests/golden/make_golden.py (the
+ * reference compiled unmodified under /tmp) and committed as data under tests/golden/: GN known-answer tests,
+ * candidate-scan cases, action codec cases, and full first-fit trajectories (tests/test_oracle_golden.py).
+ *
+ * It deliberately keeps the reference's data structures and operation order — int32 slot grid with 1 = free, per-link
+ * running-service lists in insertion order, a binary heap of departures, fp64 GN model looped span by span — so that
+ * floating-point results agree to the last bits.  Each function cites the reference lines it follows (paths relative
+ * to the reference repository root, optical_networking_gym/...).
+ *
+ * Plain C (gcc -O2 -ffp-contract=off -fopenmp).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/ongym.h"
+#include "../include/ongym_traffic.h"
+
+#define ORC_MAX_HOPS 64
+
+typedef struct {
+    int32_t id;         /* Service.service_id = episode_services_processed at creation (envs/qrmsa.pyx:1092) */
+    int32_t src, dst;
+    float arrival_time, holding_time, bit_rate; /* C floats in the reference (envs/qrmsa.pyx:35-37, 1068-1075) */
+    int32_t path_id, slot, nslots, mod;
+    double center_frequency, bandwidth, launch_power;
+    double osnr, ase, nli;
+    int accepted;
+} orc_service;
+
+typedef struct {
+    double key;    /* heap key; re-pushed entries carry the float32-rounded key (envs/qrmsa.pyx:1114-1121) */
+    int32_t id;
+    int32_t svc;   /* index into pool */
+} orc_event;
+
+typedef struct orc_env {
+    ongym_config cfg; /* pointers re-targeted to owned copies */
+    int32_t *pair_paths, *path_hops, *path_links, *link_nspans, *mod_se;
+    double *link_span_km, *link_alpha, *link_nf, *mod_thr, *bit_rates, *bit_rate_cum, *node_cum;
+    double launch_power, margin, load, mean_iat;
+    /* dynamic state */
+    int32_t *grid;          /* [E*S], 1 = free: topology.graph["available_slots"] (envs/qrmsa.pyx:306-309) */
+    orc_service *pool;      /* running services live here */
+    int32_t *pool_free, n_pool_free, pool_cap;
+    int32_t *run;           /* [E][cap] per-link running_services, insertion order (envs/qrmsa.pyx:1304-1305) */
+    int32_t *run_cnt;       /* [E] */
+    int32_t n_running;      /* len(topology.graph["running_services"]) */
+    orc_event *heap; int32_t n_heap;
+    orc_service cur;        /* current_service */
+    int new_service;        /* _new_service */
+    double current_time;
+    int max_mod_idx;
+    /* counters (envs/qrmsa.pyx:364-371, 408-410) */
+    int64_t services_processed, services_accepted, ep_processed, ep_accepted;
+    double bit_rate_requested, bit_rate_provisioned, ep_bit_rate_requested, ep_bit_rate_provisioned;
+    int64_t bl_reject, ep_mod_hist[8];
+    double ep_osnr_sum; int64_t ep_services_listed; /* for mean_gsnr: topology.graph["services"] */
+    int64_t episodes_completed;
+    ongym_stats last; /* snapshot at last terminal step */
+    int64_t total_steps, total_accepted, total_gn, total_terms;
+    /* request source */
+    int mode;               /* 0 none, 1 rng, 2 trace */
+    uint64_t key, req_index;
+    const ongym_request *trace; int64_t trace_n, trace_pos;
+    int flags;
+} orc_env;
+
+static void *dup_mem(const void *p, size_t n) { void *q = malloc(n ? n : 1); if (p && n) memcpy(q, p, n); return q; }
+
+orc_env *orc_create(const ongym_config *c, int replica) {
+    orc_env *e = (orc_env *)calloc(1, sizeof(orc_env));
+    e->cfg = *c;
+    int N = c->n_nodes, E = c->n_links, P = c->n_paths, K = c->k_paths, H = c->max_hops, M = c->n_mods;
+    e->pair_paths = dup_mem(c->pair_paths, sizeof(int32_t) * N * N * K);
+    e->path_hops = dup_mem(c->path_hops, sizeof(int32_t) * P);
+    e->path_links = dup_mem(c->path_links, sizeof(int32_t) * P * H);
+    e->link_nspans = dup_mem(c->link_nspans, sizeof(int32_t) * E);
+    e->link_span_km = dup_mem(c->link_span_km, sizeof(double) * E);
+    e->link_alpha = dup_mem(c->link_alpha, sizeof(double) * E);
+    e->link_nf = dup_mem(c->link_nf, sizeof(double) * E);
+    e->mod_se = dup_mem(c->mod_se, sizeof(int32_t) * M);
+    e->mod_thr = dup_mem(c->mod_min_osnr, sizeof(double) * M);
+    e->bit_rates = dup_mem(c->bit_rates, sizeof(double) * c->n_bit_rates);
+    e->bit_rate_cum = dup_mem(c->bit_rate_cum, sizeof(double) * c->n_bit_rates);
+    e->node_cum = dup_mem(c->node_cum, sizeof(double) * N);
+    e->launch_power = c->replica_launch_power_w ? c->replica_launch_power_w[replica] : c->launch_power_w;
+    e->margin = c->replica_margin ? c->replica_margin[replica] : c->margin;
+    e->load = c->replica_load ? c->replica_load[replica] : c->load;
+    /* set_load, envs/qrmsa.pyx:1124-1132 */
+    e->mean_iat = 1 / (e->load / c->mean_holding_time);
+    e->grid = (int32_t *)malloc(sizeof(int32_t) * E * c->n_slots);
+    e->pool_cap = c->capacity;
+    e->pool = (orc_service *)calloc(e->pool_cap, sizeof(orc_service));
+    e->pool_free = (int32_t *)malloc(sizeof(int32_t) * e->pool_cap);
+    e->run = (int32_t *)malloc(sizeof(int32_t) * E * e->pool_cap);
+    e->run_cnt = (int32_t *)calloc(E, sizeof(int32_t));
+    e->heap = (orc_event *)malloc(sizeof(orc_event) * e->pool_cap);
+    e->max_mod_idx = M - 1;
+    e->current_time = 0.0;
+    return e;
+}
+
+void orc_destroy(orc_env *e) {
+    if (!e) return;
+    free(e->pair_paths); free(e->path_hops); free(e->path_links); free(e->link_nspans); free(e->link_span_km);
+    free(e->link_alpha); free(e->link_nf); free(e->mod_se); free(e->mod_thr); free(e->bit_rates);
+    free(e->bit_rate_cum); free(e->node_cum); free(e->grid); free(e->pool); free(e->pool_free); free(e->run);
+    free(e->run_cnt); free(e->heap); free(e);
+}
+
+void orc_seed(orc_env *e, uint64_t seed, uint64_t replica) {
+    e->mode = 1; e->key = ongym_stream_key(seed, replica); e->req_index = 0;
+}
+void orc_set_trace(orc_env *e, const ongym_request *reqs, int64_t n) {
+    e->mode = 2; e->trace = reqs; e->trace_n = n; e->trace_pos = 0;
+}
+
+/* ---- departures heap: heapq of (release_time, service_id, service) (envs/qrmsa.pyx:1327-1330) ------------------ */
+static int ev_less(const orc_event *a, const orc_event *b) {
+    return a->key < b->key || (a->key == b->key && a->id < b->id);
+}
+static void heap_push(orc_env *e, orc_event ev) {
+    int i = e->n_heap++;
+    e->heap[i] = ev;
+    while (i > 0) {
+        int p = (i - 1) / 2;
+        if (!ev_less(&e->heap[i], &e->heap[p])) break;
+        orc_event t = e->heap[i]; e->heap[i] = e->heap[p]; e->heap[p] = t; i = p;
+    }
+}
+static orc_event heap_pop(orc_env *e) {
+    orc_event top = e->heap[0];
+    e->heap[0] = e->heap[--e->n_heap];
+    int i = 0;
+    for (;;) {
+        int l = 2 * i + 1, r = l + 1, m = i;
+        if (l < e->n_heap && ev_less(&e->heap[l], &e->heap[m])) m = l;
+        if (r < e->n_heap && ev_less(&e->heap[r], &e->heap[m])) m = r;
+        if (m == i) break;
+        orc_event t = e->heap[i]; e->heap[i] = e->heap[m]; e->heap[m] = t; i = m;
+    }
+    return top;
+}
+
+/* ---- _release_path (envs/qrmsa.pyx:1332-1350): frees [slot, slot+n+1) (numpy clamps at S) on every link -------- */
+static void release_path(orc_env *e, int32_t si) {
+    orc_service *s = &e->pool[si];
+    int S = e->cfg.n_slots, H = e->cfg.max_hops;
+    int hops = e->path_hops[s->path_id];
+    for (int h = 0; h < hops; h++) {
+        int l = e->path_links[s->path_id * H + h];
+        int end = s->slot + s->nslots + 1; if (end > S) end = S;
+        for (int j = s->slot; j < end; j++) e->grid[l * S + j] = 1;
+        /* list.remove(service): first match, order of the rest preserved */
+        int32_t *lst = &e->run[(size_t)l * e->pool_cap]; int n = e->run_cnt[l], k = 0;
+        while (k < n && lst[k] != si) k++;
+        for (; k + 1 < n; k++) lst[k] = lst[k + 1];
+        e->run_cnt[l] = n - 1;
+    }
+    e->n_running--;
+    e->pool_free[e->n_pool_free++] = si;
+}
+
+/* ---- get_number_slots (envs/qrmsa.pyx:1198-1205), bands unset: ceil(bit_rate / (SE * channel_width)) ----------- */
+int orc_number_slots(const orc_env *e, float bit_rate, int mod) {
+    double required = (double)bit_rate / ((double)e->mod_se[mod] * e->cfg.channel_width);
+    return (int)ceil(required);
+}
+
+/* ---- _next_service (envs/qrmsa.pyx:1067-1122) ---------------------------------------------------------------- */
+static int next_service(orc_env *e) {
+    if (e->new_service) return 0;                                  /* :1077-1078 */
+    float at, ht, br; int src, dst;
+    if (e->mode == 1) {
+        ongym_traffic_params tp = { e->mean_iat, e->cfg.mean_holding_time, e->node_cum, e->cfg.n_nodes,
+            e->cfg.bit_rate_mode, e->bit_rates, e->bit_rate_cum, e->cfg.n_bit_rates, e->cfg.bit_rate_lo,
+            e->cfg.bit_rate_hi };
+        ongym_drawn_request r = ongym_draw_request(e->key, e->req_index++, e->current_time, &tp);
+        at = r.arrival_time; ht = r.holding_time; br = r.bit_rate; src = r.source; dst = r.destination;
+    } else if (e->mode == 2) {
+        if (e->trace_pos >= e->trace_n) { e->flags |= ONGYM_F_NO_REQUEST; return -1; }
+        const ongym_request *q = &e->trace[e->trace_pos++];
+        at = q->arrival_time; ht = q->holding_time; br = q->bit_rate; src = q->source; dst = q->destination;
+    } else return -1;
+    e->current_time = at;                                          /* :1079-1081: cdef float at -> double */
+    memset(&e->cur, 0, sizeof(e->cur));
+    e->cur.id = (int32_t)e->ep_processed;                          /* :1092 */
+    e->cur.src = src; e->cur.dst = dst; e->cur.arrival_time = at; e->cur.holding_time = ht; e->cur.bit_rate = br;
+    e->cur.path_id = -1; e->cur.slot = 0; e->cur.mod = -1;
+    e->new_service = 1;
+    e->services_processed += 1; e->ep_processed += 1;              /* :1104-1105 */
+    e->bit_rate_requested += e->cur.bit_rate; e->ep_bit_rate_requested += e->cur.bit_rate; /* :1107-1108 */
+    while (e->n_heap > 0) {                                        /* :1113-1122 */
+        orc_event ev = heap_pop(e);
+        float time = (float)ev.key;                                /* `cdef float time` */
+        if (time <= e->current_time) {
+            release_path(e, ev.svc);
+        } else {
+            ev.key = time; heap_push(e, ev);
+            break;
+        }
+    }
+    return 0;
+}
+
+/* ---- reset (envs/qrmsa.pyx:427-504) --------------------------------------------------------------------------- */
+int orc_reset(orc_env *e) {
+    int E = e->cfg.n_links, S = e->cfg.n_slots;
+    e->ep_bit_rate_requested = 0.0; e->ep_bit_rate_provisioned = 0.0;
+    e->ep_processed = 0; e->ep_accepted = 0;
+    e->n_heap = 0; e->bl_reject = 0; e->max_mod_idx = e->cfg.n_mods - 1;
+    memset(e->ep_mod_hist, 0, sizeof(e->ep_mod_hist));
+    e->bit_rate_requested = 0.0; e->bit_rate_provisioned = 0.0;   /* :466-467 */
+    e->ep_osnr_sum = 0.0; e->ep_services_listed = 0;              /* topology.graph["services"] = [] */
+    e->n_running = 0; memset(e->run_cnt, 0, sizeof(int32_t) * E);
+    e->n_pool_free = 0;
+    for (int i = e->pool_cap - 1; i >= 0; i--) e->pool_free[e->n_pool_free++] = i;
+    for (int i = 0; i < E * S; i++) e->grid[i] = 1;               /* :481-484 */
+    e->new_service = 0;                                            /* :499-500 */
+    return next_service(e);
+}
+
+/* ---- get_available_slots (envs/qrmsa.pyx:1482-1512): product of the path's link rows --------------------------- */
+void orc_available(const orc_env *e, int path_id, int32_t *out) {
+    int S = e->cfg.n_slots, H = e->cfg.max_hops, hops = e->path_hops[path_id];
+    const int32_t *r0 = &e->grid[e->path_links[path_id * H] * S];
+    for (int j = 0; j < S; j++) out[j] = r0[j];
+    for (int h = 1; h < hops; h++) {
+        const int32_t *r = &e->grid[e->path_links[path_id * H + h] * S];
+        for (int j = 0; j < S; j++) out[j] *= r[j];
+    }
+}
+
+/* ---- rle (utils.pyx:44-58) + _get_candidates (envs/qrmsa.pyx:515-541) ------------------------------------------ */
+/* Walks the runs of `row` (the numpy rle returns (positions, values, lengths)); a free run [start, start+len) yields
+ * starts start..start+len-n when it touches total_slots, else start..start+len-(n+1).  Returns the count; writes up
+ * to max_out starts (ascending). */
+int orc_candidates(const int32_t *row, int total_slots, int n, int32_t *out, int max_out) {
+    int cnt = 0, i = 0;
+    while (i < total_slots) {
+        int start = i, val = row[i];
+        while (i < total_slots && row[i] == val) i++;
+        int length = i - start;
+        if (val == 1) {
+            int need = (start + length == total_slots) ? n : n + 1;
+            if (length >= need)
+                for (int c = start; c <= start + length - need; c++) { if (cnt < max_out) out[cnt] = c; cnt++; }
+        }
+    }
+    return cnt;
+}
+
+/* ---- is_path_free (envs/qrmsa.pyx:1248-1264) ------------------------------------------------------------------ */
+int orc_is_path_free(const orc_env *e, int path_id, int slot, int n) {
+    int S = e->cfg.n_slots, H = e->cfg.max_hops;
+    int end = slot + n;
+    if (end > S) return 0;
+    if (end < S) end += 1;
+    for (int h = 0; h < e->path_hops[path_id]; h++) {
+        const int32_t *r = &e->grid[e->path_links[path_id * H + h] * S];
+        for (int j = slot; j < end; j++) if (r[j] == 0) return 0;
+    }
+    return 1;
+}
+
+/* ---- calculate_osnr (core/osnr.pyx:21-142), literal: link loop, span loop, interferer loop, fp64 --------------- */
+static const double PHI_MOD[6] = {1.0, 1.0, 2.0 / 3.0, 17.0 / 25.0, 69.0 / 100.0, 13.0 / 21.0}; /* core/osnr.pyx:38-41 */
+
+typedef struct { double fc, bw; int se; int id; } orc_intf;
+
+static void gn_core(const orc_env *e, int path_id, double fc, double bw, double P, int self_id,
+                    const orc_intf *const *lists, const int *counts, double out[3], int64_t *terms) {
+    const double beta_2 = -21.3e-27, gamma = 1.3e-3, h_plank = 6.626e-34, pi = M_PI;
+    double acc_gsnr = 0.0, acc_ase = 0.0, acc_nli = 0.0;
+    int H = e->cfg.max_hops, hops = e->path_hops[path_id];
+    for (int h = 0; h < hops; h++) {
+        int l = e->path_links[path_id * H + h];
+        double alpha = e->link_alpha[l], L = e->link_span_km[l], nf = e->link_nf[l];
+        for (int sp = 0; sp < e->link_nspans[l]; sp++) {
+            double l_eff_a = 1.0 / (2.0 * alpha);
+            double l_eff = (1.0 - exp(-2.0 * alpha * L * 1e3)) / (2.0 * alpha);
+            double sum_phi = asinh(pi * pi * fabs(beta_2) * (bw * bw) / (4.0 * alpha));
+            for (int k = 0; k < counts[h]; k++) {
+                const orc_intf *r = &lists[h][k];
+                if (r->id == self_id) continue;                    /* core/osnr.pyx:65 */
+                double phi = (asinh(pi * pi * fabs(beta_2) * l_eff_a * r->bw * (r->fc - fc + (r->bw / 2.0)))
+                              - asinh(pi * pi * fabs(beta_2) * l_eff_a * r->bw * (r->fc - fc - (r->bw / 2.0))))
+                             - (PHI_MOD[r->se - 1] * (r->bw / fabs(r->fc - fc)) * (5.0 / 3.0) * (l_eff / (L * 1e3)));
+                sum_phi += phi;
+                if (terms) (*terms)++;
+            }
+            double ratio = P / bw;
+            double power_nli_span = (ratio * ratio * ratio) * (8.0 / (27.0 * pi * fabs(beta_2))) * (gamma * gamma)
+                                    * l_eff * sum_phi * bw;
+            double power_ase = bw * h_plank * fc * (exp(2.0 * alpha * L * 1e3) - 1.0) * nf;
+            acc_gsnr += 1.0 / (P / (power_ase + power_nli_span));
+            acc_ase += 1.0 / (P / power_ase);
+            acc_nli += 1.0 / (P / power_nli_span);
+        }
+    }
+    out[0] = 10.0 * log10(1.0 / acc_gsnr);
+    out[1] = 10.0 * log10(1.0 / acc_ase);
+    out[2] = 10.0 * log10(1.0 / acc_nli);
+}
+
+/* center frequency / bandwidth of an allocation (envs/qrmsa.pyx:901-906; heuristics/heuristics.py:947-952) */
+static double center_freq(const orc_env *e, int slot, int n) {
+    return e->cfg.frequency_start + (e->cfg.slot_bandwidth * slot) + (e->cfg.slot_bandwidth * (n / 2.0));
+}
+
+/* GN of a candidate against the CURRENT state */
+void orc_gn(orc_env *e, int path_id, int slot, int n, double out[3]) {
+    int H = e->cfg.max_hops, hops = e->path_hops[path_id];
+    const orc_intf *lists[ORC_MAX_HOPS]; int counts[ORC_MAX_HOPS];
+    orc_intf *buf = (orc_intf *)malloc(sizeof(orc_intf) * (size_t)(e->n_running + 1) * hops);
+    size_t off = 0;
+    for (int h = 0; h < hops; h++) {
+        int l = e->path_links[path_id * H + h];
+        lists[h] = &buf[off]; counts[h] = e->run_cnt[l];
+        for (int k = 0; k < e->run_cnt[l]; k++) {
+            const orc_service *s = &e->pool[e->run[(size_t)l * e->pool_cap + k]];
+            buf[off].fc = s->center_frequency; buf[off].bw = s->bandwidth; buf[off].se = e->mod_se[s->mod];
+            buf[off].id = s->id; off++;
+        }
+    }
+    e->total_gn++;
+    gn_core(e, path_id, center_freq(e, slot, n), e->cfg.slot_bandwidth * n, e->launch_power, -1, lists, counts, out,
+            &e->total_terms);
+    free(buf);
+}
+
+/* GN with explicit per-link interferer lists (for the captured known-answer tests):
+ * intf = flat (slot, n, se) triples, link h owns counts[h] consecutive triples. */
+void orc_gn_lists(orc_env *e, int path_id, int slot, int n, const int32_t *counts_in, const int16_t *intf,
+                  double out[3]) {
+    int hops = e->path_hops[path_id];
+    const orc_intf *lists[ORC_MAX_HOPS]; int counts[ORC_MAX_HOPS];
+    size_t total = 0;
+    for (int h = 0; h < hops; h++) total += counts_in[h];
+    orc_intf *buf = (orc_intf *)malloc(sizeof(orc_intf) * (total + 1));
+    size_t off = 0;
+    for (int h = 0; h < hops; h++) {
+        lists[h] = &buf[off]; counts[h] = counts_in[h];
+        for (int k = 0; k < counts_in[h]; k++, off++) {
+            buf[off].fc = center_freq(e, intf[off * 3], intf[off * 3 + 1]);
+            buf[off].bw = e->cfg.slot_bandwidth * intf[off * 3 + 1];
+            buf[off].se = intf[off * 3 + 2]; buf[off].id = 1000000 + (int)off;
+        }
+    }
+    gn_core(e, path_id, center_freq(e, slot, n), e->cfg.slot_bandwidth * n, e->launch_power, -1, lists, counts, out, 0);
+    free(buf);
+}
+
+/* ---- action codec (heuristics/heuristics.py:36-54; envs/qrmsa.pyx:801-834) ------------------------------------- */
+int orc_encode_action(const orc_env *e, int path_index, int mod_index, int slot) {
+    int rel = e->max_mod_idx - mod_index;
+    return path_index * e->cfg.n_mods * e->cfg.n_slots + rel * e->cfg.n_slots + slot;
+}
+void orc_decode_action(const orc_env *e, int action, int out[3]) {
+    int M = e->cfg.n_mods, S = e->cfg.n_slots, K = e->cfg.k_paths;
+    int slot = action % S; action /= S;
+    int r = action % M; action /= M;
+    int route = action % K;
+    int mod = (e->max_mod_idx > 1) ? e->max_mod_idx - r : (M - 1) - r;  /* :821-825 */
+    out[0] = route; out[1] = mod; out[2] = slot;
+}
+int orc_reject_action(const orc_env *e) { return e->cfg.k_paths * e->cfg.n_mods * e->cfg.n_slots; }
+
+/* ---- heuristic_shortest_available_path_first_fit_best_modulation (heuristics/heuristics.py:923-966) ------------ */
+int orc_policy_first_fit(orc_env *e, int *blocked_resources, int *blocked_osnr) {
+    int bres = 0, bosnr = 0;
+    int S = e->cfg.n_slots, K = e->cfg.k_paths, N = e->cfg.n_nodes;
+    int32_t *avail = (int32_t *)malloc(sizeof(int32_t) * S);
+    int action = orc_reject_action(e);
+    for (int k = 0; k < K; k++) {
+        int p = e->pair_paths[(e->cur.src * N + e->cur.dst) * K + k];
+        if (p < 0) break;                                          /* fewer than k paths exist */
+        for (int m = e->max_mod_idx; m >= 0; m--) {
+            int req = orc_number_slots(e, e->cur.bit_rate, m);
+            if (req <= 0) continue;
+            orc_available(e, p, avail);
+            int32_t first;
+            int cnt = orc_candidates(avail, S, req, &first, 1);
+            if (cnt == 0) { bres = 1; continue; }
+            double o[3];
+            orc_gn(e, p, first, req, o);
+            double threshold = e->mod_thr[m] + e->margin;
+            if (o[0] >= threshold) {
+                action = orc_encode_action(e, k, m, first);
+                free(avail);
+                *blocked_resources = 0; *blocked_osnr = 0;
+                return action;
+            }
+            bosnr = 1;
+            if (bres) bres = 0;
+        }
+    }
+    free(avail);
+    *blocked_resources = bres; *blocked_osnr = bosnr;
+    return action;
+}
+
+/* ---- reward (envs/qrmsa.pyx:1266-1285): only the not-accepted branch returns a value (quirk Q1) --------------- */
+static double reward(const orc_env *e) {
+    double failed_ratio = (double)(e->ep_processed - e->ep_accepted) / (double)e->ep_processed;
+    if (!e->cur.accepted) return -3.0 * (1.0 + failed_ratio);
+    return 0.0;
+}
+
+/* ---- _provision_path + _add_release (envs/qrmsa.pyx:1288-1330) -------------------------------------------------- */
+static int provision(orc_env *e, int path_id, int slot, int n) {
+    int S = e->cfg.n_slots, H = e->cfg.max_hops;
+    if (e->n_pool_free == 0) { e->flags |= ONGYM_F_OVERFLOW; return -1; }
+    int end = slot + n;
+    if (end < S) end += 1;
+    int32_t si = e->pool_free[--e->n_pool_free];
+    e->cur.path_id = path_id; e->cur.slot = slot; e->cur.nslots = n;
+    e->cur.center_frequency = center_freq(e, slot, n);
+    e->cur.bandwidth = e->cfg.slot_bandwidth * n;
+    e->pool[si] = e->cur;
+    for (int h = 0; h < e->path_hops[path_id]; h++) {
+        int l = e->path_links[path_id * H + h];
+        for (int j = slot; j < end; j++) e->grid[l * S + j] = 0;
+        e->run[(size_t)l * e->pool_cap + e->run_cnt[l]++] = si;
+    }
+    e->n_running++;
+    e->services_accepted += 1; e->ep_accepted += 1;
+    e->bit_rate_provisioned += e->cur.bit_rate;
+    e->ep_bit_rate_provisioned = (double)(int64_t)(e->ep_bit_rate_provisioned + e->cur.bit_rate); /* :1319-1321 */
+    orc_event ev; ev.key = (double)(e->cur.arrival_time + e->cur.holding_time); /* float + float, :1329 */
+    ev.id = e->cur.id; ev.svc = si;
+    heap_push(e, ev);
+    return 0;
+}
+
+static void snapshot_terminal(orc_env *e) {
+    ongym_stats *s = &e->last;
+    s->last_episode_processed = e->ep_processed; s->last_episode_accepted = e->ep_accepted;
+    s->last_rejected = e->bl_reject;
+    s->last_service_blocking_rate = e->services_processed > 0
+        ? (double)(e->services_processed - e->services_accepted) / (double)e->services_processed : 0.0;
+    s->last_episode_service_blocking_rate = e->ep_processed > 0
+        ? (double)(e->ep_processed - e->ep_accepted) / (double)e->ep_processed : 0.0;
+    s->last_bit_rate_blocking_rate = e->bit_rate_requested > 0
+        ? (e->bit_rate_requested - e->bit_rate_provisioned) / e->bit_rate_requested : 0.0;
+    s->last_episode_bit_rate_blocking_rate = e->ep_bit_rate_requested > 0
+        ? (e->ep_bit_rate_requested - e->ep_bit_rate_provisioned) / e->ep_bit_rate_requested : 0.0;
+    memcpy(s->last_modulation_hist, e->ep_mod_hist, sizeof(e->ep_mod_hist));
+    s->last_mean_gsnr = e->ep_services_listed ? e->ep_osnr_sum / (double)e->ep_services_listed : 0.0;
+}
+
+/* ---- step (envs/qrmsa.pyx:838-1065), gen_observation=False, measure_disruptions=False, no CSV ------------------ */
+int orc_step(orc_env *e, int action, ongym_step_rec *out) {
+    ongym_step_rec r; memset(&r, 0, sizeof(r));
+    r.action = action; r.route = -1; r.modulation = -1; r.slot = -1;
+    int reject = orc_reject_action(e);
+    double osnr = 0.0;
+    if (action == reject) {
+        e->cur.accepted = 0; e->bl_reject += 1;                   /* :861-865 */
+    } else {
+        int d[3]; orc_decode_action(e, action, d);
+        int route = d[0], m = d[1], slot = d[2];
+        int N = e->cfg.n_nodes, K = e->cfg.k_paths;
+        int p = e->pair_paths[(e->cur.src * N + e->cur.dst) * K + route];
+        int n = orc_number_slots(e, e->cur.bit_rate, m);
+        double osnr_req = e->mod_thr[m] + e->margin;
+        if (p < 0 || !orc_is_path_free(e, p, slot, n)) {          /* :886-897 (quirk Q5) */
+            e->cur.accepted = 0;
+            r.reward = reward(e); r.retry = 1; r.flags |= ONGYM_F_BLOCKED_RESOURCES;
+            r.active = e->n_running;
+            if (out) *out = r;
+            return 0;
+        }
+        double o[3];
+        orc_gn(e, p, slot, n, o);                                  /* :909 */
+        r.route = (int16_t)route; r.slot = (int16_t)slot;
+        if (o[0] >= osnr_req) {                                    /* :911-924 */
+            e->cur.accepted = 1; e->cur.osnr = o[0]; e->cur.ase = o[1]; e->cur.nli = o[2]; e->cur.mod = m;
+            e->cur.launch_power = e->launch_power;
+            e->ep_mod_hist[m] += 1;
+            if (provision(e, p, slot, n) < 0) { e->cur.accepted = 0; r.flags |= ONGYM_F_OVERFLOW; }
+            else { r.modulation = (int16_t)m; r.nslots = (int16_t)n; r.osnr = o[0]; r.ase = o[1]; r.nli = o[2];
+                   osnr = o[0]; e->total_accepted++; }
+        } else {                                                   /* :925-929: raises ValueError */
+            r.flags |= ONGYM_F_QOT_ERROR; r.osnr = o[0];
+            if (out) *out = r;
+            return ONGYM_E_STATE;
+        }
+    }
+    r.accepted = (uint8_t)e->cur.accepted;
+    if (!e->cur.accepted) { r.route = (action == reject) ? -1 : r.route; }
+    r.reward = (action != reject) ? reward(e) : -6.0;              /* :992-995 */
+    e->ep_osnr_sum += e->cur.accepted ? osnr : 0.0;               /* Service.OSNR is reset to 0 when not accepted :963 */
+    e->ep_services_listed += 1;                                    /* :1053 */
+    e->new_service = 0;                                            /* :1052 */
+    e->total_steps++;
+    /* info rates are computed BEFORE _next_service (:996-1050) */
+    int will_terminate = (e->ep_processed + 1 == e->cfg.episode_length);
+    if (will_terminate) snapshot_terminal(e);
+    next_service(e);                                               /* :1054 */
+    r.terminated = (uint8_t)(e->ep_processed == e->cfg.episode_length); /* :1056 */
+    if (r.terminated) e->episodes_completed++;
+    r.active = e->n_running;
+    if (out) *out = r;
+    return 0;
+}
+
+void orc_stats(const orc_env *e, ongym_stats *s) {
+    *s = e->last;
+    s->services_processed = e->services_processed; s->services_accepted = e->services_accepted;
+    s->episode_services_processed = e->ep_processed; s->episode_services_accepted = e->ep_accepted;
+    s->bit_rate_requested = e->bit_rate_requested; s->bit_rate_provisioned = e->bit_rate_provisioned;
+    s->episode_bit_rate_requested = e->ep_bit_rate_requested;
+    s->episode_bit_rate_provisioned = e->ep_bit_rate_provisioned;
+    s->rejected = e->bl_reject;
+    memcpy(s->episode_modulation_hist, e->ep_mod_hist, sizeof(e->ep_mod_hist));
+    s->episode_osnr_sum = e->ep_osnr_sum; s->episodes_completed = e->episodes_completed;
+    s->total_steps = e->total_steps; s->total_accepted = e->total_accepted; s->total_gn_evals = e->total_gn;
+    s->total_interferer_terms = e->total_terms; s->current_time = e->current_time; s->active = e->n_running;
+    s->flags = e->flags;
+}
+
+void orc_grid(const orc_env *e, int32_t *out) {
+    memcpy(out, e->grid, sizeof(int32_t) * e->cfg.n_links * e->cfg.n_slots);
+}
+void orc_request(const orc_env *e, ongym_request *q) {
+    q->arrival_time = e->cur.arrival_time; q->holding_time = e->cur.holding_time; q->bit_rate = e->cur.bit_rate;
+    q->source = (int16_t)e->cur.src; q->destination = (int16_t)e->cur.dst;
+}
+/* running services in global insertion order is not kept by the reference beyond a list; export unordered set */
+int orc_services(const orc_env *e, ongym_service *out) {
+    int n = 0;
+    for (int i = 0; i < e->n_heap; i++) {
+        const orc_service *s = &e->pool[e->heap[i].svc];
+        out[n].path_id = s->path_id; out[n].slot = (int16_t)s->slot; out[n].nslots = (int16_t)s->nslots;
+        out[n].modulation = (int16_t)s->mod; out[n].reserved = 0; out[n].release_time = (float)e->heap[i].key; n++;
+    }
+    return n;
+}
+
+/* ---- the JOCN loop (examples/JOCN_Benchmark_2024/graph_load.py:157-164) for one replica ------------------------ */
+/* nsteps iterations of {policy, step}; auto-reset after a terminal step.  out: [nsteps] or NULL. */
+int orc_run_first_fit(orc_env *e, int nsteps, ongym_step_rec *out) {
+    for (int i = 0; i < nsteps; i++) {
+        int bres, bosnr;
+        int a = orc_policy_first_fit(e, &bres, &bosnr);
+        ongym_step_rec r;
+        int rc = orc_step(e, a, &r);
+        if (rc) return rc;
+        if (bres) r.flags |= ONGYM_F_BLOCKED_RESOURCES;
+        if (bosnr) r.flags |= ONGYM_F_BLOCKED_OSNR;
+        if (out) out[i] = r;
+        if (r.terminated && e->cfg.auto_reset) orc_reset(e);
+    }
+    return 0;
+}
+
+/* B independent replicas, OpenMP over replicas (the reference's own fan-out is one process per simulation,
+ * graph_load.py:361-363).  Used as bench.py's cpu_baseline ("port").  Returns total steps executed. */
+int64_t orc_batch_run_first_fit(orc_env **envs, int batch, int nsteps, int threads) {
+    int64_t total = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : total)
+    for (int b = 0; b < batch; b++) {
+        if (orc_run_first_fit(envs[b], nsteps, 0) == 0) total += nsteps;
+    }
+    return total;
+}

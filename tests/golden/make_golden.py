@@ -1,0 +1,421 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (runs ONLY in the build container, never on the GPU box).
+
+It compiles an untouched copy of the reference (LEA-UFPA/optical-networking-gym, mounted read-only at
+/root/reference) under /tmp, imports it, drives it exactly like examples/JOCN_Benchmark_2024/graph_load.py:157-164
+(`action,_,_ = heuristic(env); env.step(action)`) and writes small data fixtures (inputs + expected outputs) next to
+this file.  Nothing from the reference is copied into the repository: the fixtures hold numbers only.
+
+    python tests/golden/make_golden.py            # all fixtures
+    python tests/golden/make_golden.py traj_nsfnet320   # one fixture
+
+Determinism: the reference's traffic RNG is `random.Random()` without a seed (qrmsa.pyx:241); the harness swaps
+`random.Random` for a subclass whose no-arg constructor seeds a fixed value just before constructing the env.
+
+`gymnasium` is not installed in the container; the reference's hot path only touches
+spaces.Discrete(n).n, spaces.Box(...).shape, utils.seeding.np_random and envs.registration.register
+(qrmsa.pyx:10-11,319-335,347; wrappers/qrmsa_gym.py:4-6,19-22) so a throw-away stub package is written under /tmp.
+"""
+import json
+import os
+import random
+import shutil
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+WORK = "/tmp/ongym_ref_build"
+OUR_TOPOLOGIES = os.path.join(REPO, "optical-networking-gym_amd", "optical_networking_gym", "topologies")
+
+
+def build_reference():
+    """Appendix-B recipe of SURVEY.md: copy to /tmp, build_ext --inplace with the reference's own flags."""
+    marker = os.path.join(WORK, "optical_networking_gym", "envs")
+    have = os.path.isdir(marker) and any(f.startswith("qrmsa.") and f.endswith(".so") for f in os.listdir(marker))
+    if not have:
+        if os.path.isdir(WORK):
+            shutil.rmtree(WORK)
+        os.makedirs(WORK)
+        for name in ("optical_networking_gym", "setup.py", "pyproject.toml", "README.md"):
+            src = os.path.join(REF, name)
+            dst = os.path.join(WORK, name)
+            if os.path.isdir(src):
+                shutil.copytree(src, dst)
+            else:
+                shutil.copy(src, dst)
+        subprocess.run(["chmod", "-R", "u+w", WORK], check=True)
+        subprocess.run([sys.executable, "setup.py", "build_ext", "--inplace"], cwd=WORK, check=True,
+                       stdout=subprocess.DEVNULL)
+    stub = os.path.join(WORK, "_stubs", "gymnasium")
+    if not os.path.isdir(stub):
+        os.makedirs(os.path.join(stub, "utils"))
+        os.makedirs(os.path.join(stub, "envs"))
+        open(os.path.join(stub, "__init__.py"), "w").write(textwrap.dedent("""
+            from . import spaces
+            class Env:
+                pass
+            class Wrapper(Env):
+                def __init__(self, env):
+                    self.env = env
+            """))
+        open(os.path.join(stub, "spaces.py"), "w").write(textwrap.dedent("""
+            class Discrete:
+                def __init__(self, n): self.n = int(n)
+            class Box:
+                def __init__(self, low, high, shape, dtype=None): self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), dtype
+            """))
+        open(os.path.join(stub, "utils", "__init__.py"), "w").write("")
+        open(os.path.join(stub, "utils", "seeding.py"), "w").write(textwrap.dedent("""
+            import numpy as np
+            def np_random(seed=None):
+                ss = np.random.SeedSequence(seed)
+                return np.random.Generator(np.random.PCG64(ss)), ss.entropy
+            """))
+        open(os.path.join(stub, "envs", "__init__.py"), "w").write("")
+        open(os.path.join(stub, "envs", "registration.py"), "w").write("def register(*a, **k):\n    return None\n")
+    sys.path.insert(0, os.path.join(WORK, "_stubs"))
+    sys.path.insert(0, WORK)
+
+
+build_reference()
+import networkx  # noqa: E402  (must be imported BEFORE random.Random is patched, networkx/utils/misc.py seeds at import)
+from optical_networking_gym.topology import Modulation, get_topology  # noqa: E402
+from optical_networking_gym.wrappers.qrmsa_gym import QRMSAEnvWrapper  # noqa: E402
+import optical_networking_gym.heuristics.heuristics as H  # noqa: E402
+from optical_networking_gym.core.osnr import calculate_osnr  # noqa: E402
+
+_OrigRandom = random.Random
+
+
+def seeded_random(seed):
+    class _Seeded(_OrigRandom):
+        def __init__(self, x=None):
+            super().__init__(seed if x is None else x)
+    return _Seeded
+
+
+def jocn_modulations():
+    # thresholds of examples/JOCN_Benchmark_2024/graph_load.py:252-295
+    return (Modulation("BPSK", 100000, 1, 3.71, -14), Modulation("QPSK", 2000, 2, 6.72, -17),
+            Modulation("8QAM", 1000, 3, 10.84, -20), Modulation("16QAM", 500, 4, 13.24, -23),
+            Modulation("32QAM", 250, 5, 16.16, -26), Modulation("64QAM", 125, 6, 19.01, -29))
+
+
+TOPO_FILES = {
+    "nsfnet": os.path.join(REF, "examples/topologies/nsfnet_chen.txt"),
+    "nobel-eu": os.path.join(REF, "examples/topologies/nobel-eu.xml"),
+    "germany50": os.path.join(REF, "examples/topologies/germany50.xml"),
+    "ring4": os.path.join(REF, "examples/topologies/ring_4.txt"),
+    "cost239": os.path.join(OUR_TOPOLOGIES, "cost239.txt"),   # authored here; the reference parses any .txt
+}
+
+
+def load_topology(name, k=5, max_span=80, att=0.2, nf=4.5):
+    return get_topology(TOPO_FILES[name], name, jocn_modulations(), max_span, att, nf, k)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# static tables
+# ----------------------------------------------------------------------------------------------------------------
+def export_tables(name, k=5):
+    topo = load_topology(name, k)
+    nodes = list(topo.nodes())
+    nidx = {n: i for i, n in enumerate(nodes)}
+    edges = []
+    for a, b in topo.edges():
+        d = topo[a][b]
+        lk = d["link"]
+        sp = lk.spans[0]
+        assert all(s.length == sp.length for s in lk.spans)
+        edges.append(dict(index=int(d["index"]), a=nidx[a], b=nidx[b], length=float(d["length"]),
+                          nspans=len(lk.spans), span_km=float(sp.length), alpha=float(sp.attenuation_normalized),
+                          nf=float(sp.noise_figure_normalized)))
+    edges.sort(key=lambda e: e["index"])
+    pairs = {}
+    ksp = topo.graph["ksp"]
+    for i, a in enumerate(nodes):
+        for j, b in enumerate(nodes):
+            if i < j:
+                pl = []
+                for p in ksp[a, b]:
+                    pl.append(dict(id=int(p.id), k=int(p.k), nodes=[nidx[n] for n in p.node_list],
+                                   links=[int(l.id) for l in p.links], hops=int(p.hops), length=float(p.length)))
+                pairs[f"{i},{j}"] = pl
+    out = dict(name=name, k_paths=k, node_names=nodes, edges=edges, pairs=pairs, max_span=80, att=0.2, nf_db=4.5)
+    if name == "nobel-eu":
+        # node coordinates so that the repo can carry nobel-eu as a plain .txt (lengths are what matters)
+        out["xml_lengths_km"] = [e["length"] for e in edges]
+    json.dump(out, open(os.path.join(HERE, f"tables_{name}.json"), "w"), separators=(",", ":"))
+    print("tables", name, len(nodes), "nodes", len(edges), "edges", sum(len(v) for v in pairs.values()), "paths")
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# trajectories
+# ----------------------------------------------------------------------------------------------------------------
+def request_tuple(env):
+    s = env.env.current_service
+    return (float(s.arrival_time), float(s.holding_time), int(s.source_id), int(s.destination_id), float(s.bit_rate))
+
+
+def link_state(env, link):
+    """(slot, n, SE) of the running services of a link, in the reference's list order."""
+    rs = env.env.topology[link.node1][link.node2]["running_services"]
+    return [(int(x.initial_slot), int(x.number_slots), int(x.current_modulation.spectral_efficiency)) for x in rs]
+
+
+def run_trajectory(tag, topo_name, seed, load, S, episodes, episode_length=1000, bit_rates=(10, 40, 100, 400),
+                   launch_power_dbm=0.0, margin=0.0, bit_rate_selection="discrete", scripted=False,
+                   gn_every=41, snap_steps=(100, 400, 700, 998), k=5):
+    topo = load_topology(topo_name, k)
+    nodes = list(topo.nodes())
+    gn_samples = []
+    gn_counter = [0]
+    orig = H.calculate_osnr
+
+    def recording_osnr(env_, svc):
+        r = orig(env_, svc)
+        gn_counter[0] += 1
+        if gn_counter[0] % gn_every == 0:
+            links = [(int(l.id), link_state(wrapper, l)) for l in svc.path.links]
+            gn_samples.append(dict(path_id=int(svc.path.id), slot=int(svc.initial_slot), n=int(svc.number_slots),
+                                   links=links, out=[float(r[0]), float(r[1]), float(r[2])]))
+        return r
+
+    H.calculate_osnr = recording_osnr
+    random.Random = seeded_random(seed)
+    try:
+        wrapper = QRMSAEnvWrapper(
+            topology=topo, seed=10, allow_rejection=True, load=load, episode_length=episode_length,
+            num_spectrum_resources=S, launch_power_dbm=launch_power_dbm, bandwidth=S * 12.5e9,
+            frequency_start=3e8 / 1565e-9, frequency_slot_bandwidth=12.5e9, bit_rate_selection=bit_rate_selection,
+            bit_rates=bit_rates, bit_rate_lower_bound=25, bit_rate_higher_bound=100, margin=margin, file_name="",
+            measure_disruptions=False, k_paths=k, modulations_to_consider=6, defragmentation=False,
+            n_defrag_services=0, gen_observation=False)
+    finally:
+        random.Random = _OrigRandom
+    env = wrapper
+    reqs, kinds = [], []
+    reqs.append(request_tuple(env)); kinds.append(0)   # drawn by the constructor's own reset() (qrmsa.pyx:414-415)
+    env.reset()  # graph_load.py:129-130
+    reqs.append(request_tuple(env)); kinds.append(0)
+    steps = []
+    snaps, snap_at = [], []
+    terminal_infos = []
+    M = 6
+    reject = env.env.reject_action
+    gstep = 0
+    for ep in range(episodes):
+        env.reset()  # graph_load.py:158
+        reqs.append(request_tuple(env)); kinds.append(0)
+        done = False
+        estep = 0
+        while not done:
+            cur = env.env.current_service
+            action, bres, bosnr = H.heuristic_shortest_available_path_first_fit_best_modulation(env)
+            retry = 0
+            if scripted:
+                if gstep % 7 == 3:
+                    action, bres, bosnr = reject, False, False
+                elif gstep % 11 == 5 and action != reject:
+                    # an action whose slot range is occupied (quirk Q5, qrmsa.pyx:886-897): same path/modulation as
+                    # first-fit, but starting one slot before the first busy slot of the path
+                    route, mod, slot = env.env.encoded_decimal_to_array(action)
+                    path = env.env.k_shortest_paths[cur.source, cur.destination][route]
+                    avail = env.env.get_available_slots(path)
+                    busy = np.where(avail == 0)[0]
+                    if len(busy) and busy[0] >= 1:
+                        n_req = env.env.get_number_slots(cur, env.env.modulations[mod])
+                        assert not env.env.is_path_free(path, int(busy[0]) - 1, n_req)
+                        action = H.get_action_index(env.env, route, mod, int(busy[0]) - 1)
+                        retry = 1
+            _, reward, done, _, info = env.step(int(action))
+            if retry:
+                assert env.env.current_service is cur
+                steps.append(dict(action=int(action), accepted=0, route=-1, mod=-1, slot=-1, n=0, osnr=0.0, ase=0.0,
+                                  nli=0.0, reward=float(reward), term=0, bres=int(bool(bres)), bosnr=int(bool(bosnr)),
+                                  active=len(env.env.topology.graph["running_services"]), retry=1,
+                                  ep_acc=-1))
+                gstep += 1
+                continue
+            svc = env.env.topology.graph["services"][-1]
+            assert svc is cur
+            mod_idx = -1
+            if svc.accepted:
+                mod_idx = [m.spectral_efficiency for m in env.env.modulations].index(
+                    svc.current_modulation.spectral_efficiency)
+            steps.append(dict(action=int(action), accepted=int(svc.accepted), route=int(info["chosen_path_index"]),
+                              mod=mod_idx, slot=int(info["chosen_slot"]), n=int(svc.number_slots),
+                              osnr=float(svc.OSNR), ase=float(svc.ASE), nli=float(svc.NLI), reward=float(reward),
+                              term=int(done), bres=int(bool(bres)), bosnr=int(bool(bosnr)),
+                              active=len(env.env.topology.graph["running_services"]), retry=0,
+                              ep_acc=int(info["episode_services_accepted"])))
+            reqs.append(request_tuple(env)); kinds.append(1)
+            if ep == 0 and estep in snap_steps:
+                grid = np.asarray(env.env.topology.graph["available_slots"], dtype=np.uint8)
+                snaps.append(np.packbits(grid, axis=1, bitorder="little")); snap_at.append(gstep)
+            if done:
+                ti = {k_: (float(v) if not isinstance(v, (int, np.integer)) else int(v))
+                      for k_, v in info.items() if k_ != "mask"}
+                svcs = env.env.topology.graph["services"]
+                ti["mean_gsnr"] = float(sum(s.OSNR for s in svcs) / len(svcs))   # graph_load.py:181-185
+                ti["n_services"] = len(svcs)
+                terminal_infos.append(ti)
+            estep += 1
+            gstep += 1
+    H.calculate_osnr = orig
+    # flatten
+    reqs_a = np.array(reqs, dtype=np.float64)
+    out = dict(
+        req_at=reqs_a[:, 0].astype(np.float32), req_ht=reqs_a[:, 1].astype(np.float32),
+        req_src=reqs_a[:, 2].astype(np.int32), req_dst=reqs_a[:, 3].astype(np.int32),
+        req_br=reqs_a[:, 4].astype(np.float32), req_kind=np.array(kinds, dtype=np.uint8))
+    for key, dt in (("action", np.int32), ("accepted", np.uint8), ("route", np.int8), ("mod", np.int8),
+                    ("slot", np.int16), ("n", np.int16), ("osnr", np.float64), ("ase", np.float64),
+                    ("nli", np.float64), ("reward", np.float64), ("term", np.uint8), ("bres", np.uint8),
+                    ("bosnr", np.uint8), ("active", np.int32), ("retry", np.uint8), ("ep_acc", np.int32)):
+        out["st_" + key] = np.array([s[key] for s in steps], dtype=dt)
+    if snaps:
+        out["snap_step"] = np.array(snap_at, dtype=np.int32)
+        out["snap_grid"] = np.stack(snaps)
+    # GN samples: ragged -> flat
+    g_path, g_slot, g_n, g_out, g_off, g_link, g_cnt, flat = [], [], [], [], [], [], [], []
+    for g in gn_samples:
+        g_path.append(g["path_id"]); g_slot.append(g["slot"]); g_n.append(g["n"]); g_out.append(g["out"])
+        g_off.append(len(g_link))
+        for lid, lst in g["links"]:
+            g_link.append(lid); g_cnt.append(len(lst)); flat.extend(lst)
+    g_off.append(len(g_link))
+    out.update(gn_path=np.array(g_path, np.int32), gn_slot=np.array(g_slot, np.int32), gn_n=np.array(g_n, np.int32),
+               gn_out=np.array(g_out, np.float64).reshape(-1, 3), gn_linkoff=np.array(g_off, np.int32),
+               gn_link=np.array(g_link, np.int32), gn_cnt=np.array(g_cnt, np.int32),
+               gn_intf=np.array(flat, np.int16).reshape(-1, 3))
+    meta = dict(tag=tag, topology=topo_name, seed=seed, load=load, S=S, episodes=episodes,
+                episode_length=episode_length, bit_rates=list(bit_rates), launch_power_dbm=launch_power_dbm,
+                margin=margin, bit_rate_selection=bit_rate_selection, scripted=scripted, k_paths=k,
+                frequency_start=3e8 / 1565e-9, slot_bw=12.5e9, mean_holding=10800.0,
+                terminal_infos=terminal_infos, n_steps=len(steps), n_requests=len(reqs),
+                launch_power_w=float(env.env.launch_power), reject_action=int(reject), initial_resets=3)
+    np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **out)
+    json.dump(meta, open(os.path.join(HERE, f"{tag}.json"), "w"), indent=1)
+    acc = out["st_accepted"].mean()
+    print(f"{tag}: {len(steps)} steps, {len(reqs)} requests, accepted {acc:.4f}, GN samples {len(gn_samples)}, "
+          f"peak active {out['st_active'].max()}")
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# known-answer tests for the primitives
+# ----------------------------------------------------------------------------------------------------------------
+def export_kats():
+    topo = load_topology("nsfnet")
+    random.Random = seeded_random(1234)
+    try:
+        env = QRMSAEnvWrapper(topology=topo, seed=10, allow_rejection=True, load=300, episode_length=1000,
+                              num_spectrum_resources=320, launch_power_dbm=0.0, bandwidth=4e12,
+                              frequency_start=3e8 / 1565e-9, frequency_slot_bandwidth=12.5e9,
+                              bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), margin=0, file_name="",
+                              k_paths=5, modulations_to_consider=6, gen_observation=False)
+    finally:
+        random.Random = _OrigRandom
+    e = env.env
+    rng = np.random.default_rng(7)
+    kats = dict()
+    # (1) candidate scan + rle (qrmsa.pyx:515-541, utils.pyx:44-58)
+    cand = []
+    for _ in range(120):
+        S = int(rng.choice([12, 64, 65, 127, 320, 768]))
+        p = float(rng.choice([0.05, 0.3, 0.6, 0.9]))
+        row = (rng.random(S) > p).astype(np.int32)
+        n = int(rng.integers(1, 40))
+        starts = e._get_candidates(row, n, S)
+        cand.append(dict(row=np.packbits(row.astype(np.uint8), bitorder="little").tolist(), S=S, n=n,
+                         starts=[int(x) for x in starts]))
+    cand.append(dict(row=np.packbits(np.array([1, 1, 1, 0, 1, 1, 1, 1, 0, 1, 1, 1], np.uint8), bitorder="little").tolist(),
+                     S=12, n=2, starts=[int(x) for x in e._get_candidates(np.array([1, 1, 1, 0, 1, 1, 1, 1, 0, 1, 1, 1]), 2, 12)]))
+    for S in (12, 320):
+        for row in (np.ones(S, np.int32), np.zeros(S, np.int32)):
+            for n in (1, 5, S):
+                cand.append(dict(row=np.packbits(row.astype(np.uint8), bitorder="little").tolist(), S=S, n=n,
+                                 starts=[int(x) for x in e._get_candidates(row, n, S)]))
+    kats["candidates"] = cand
+    # (2) slots needed (qrmsa.pyx:1198-1205)
+    ns = []
+
+    class _S:  # duck-typed service: get_number_slots only reads .bit_rate
+        pass
+    for br in (10, 40, 100, 400, 1000, 25, 37, 99, 12.5, 75):
+        s = _S(); s.bit_rate = np.float32(br)
+        ns.append(dict(bit_rate=float(br), slots=[int(e.get_number_slots(s, m)) for m in e.modulations]))
+    kats["number_slots"] = ns
+    # (3) GN on the empty network (osnr.pyx:21-142), every modulation, several paths and slots
+    gn = []
+    svc = e.current_service
+    pairs = [("1", "13"), ("1", "2"), ("13", "14"), ("3", "12"), ("2", "11")]
+    for (a, b) in pairs:
+        for kidx, path in enumerate(e.k_shortest_paths[a, b]):
+            for br in (10.0, 100.0, 400.0):
+                s = _S(); s.bit_rate = np.float32(br)
+                for mi, m in enumerate(e.modulations):
+                    n = e.get_number_slots(s, m)
+                    for slot in (0, 100, 320 - n):
+                        svc.path = path; svc.initial_slot = slot; svc.number_slots = n
+                        svc.center_frequency = e.frequency_start + (e.frequency_slot_bandwidth * slot) + (
+                            e.frequency_slot_bandwidth * (n / 2))
+                        svc.bandwidth = e.frequency_slot_bandwidth * n
+                        svc.launch_power = e.launch_power
+                        r = calculate_osnr(e, svc)
+                        gn.append(dict(path_id=int(path.id), slot=slot, n=int(n), out=[float(x) for x in r]))
+    kats["gn_empty"] = gn
+    # (4) action codec (qrmsa.pyx:801-834, heuristics.py:36-54)
+    codec = []
+    for a in [0, 1, 319, 320, 960, 1037, 1227, 1919, 1920, 5000, 9599]:
+        codec.append(dict(action=a, decoded=[int(x) for x in e.encoded_decimal_to_array(a)]))
+    for (p, m, s) in [(0, 5, 0), (0, 2, 0), (4, 0, 319), (2, 3, 17)]:
+        codec.append(dict(encode=[p, m, s], action=int(H.get_action_index(e, p, m, s))))
+    kats["codec"] = codec
+    kats["constants"] = dict(frequency_start=float(e.frequency_start), launch_power_w=float(e.launch_power),
+                             reject_action=int(e.reject_action), action_n=int(e.action_space.n),
+                             obs_dim=int(e.observation_space.shape[0]))
+    # (5) request #0 of a twin CPython generator: pins the draw order (qrmsa.pyx:1079-1089,1137-1145)
+    s0 = e.current_service
+    kats["request0_seed1234"] = dict(arrival_time=float(s0.arrival_time), holding_time=float(s0.holding_time),
+                                     source_id=int(s0.source_id), destination_id=int(s0.destination_id),
+                                     bit_rate=float(s0.bit_rate), load=300.0, mean_holding=10800.0)
+    json.dump(kats, open(os.path.join(HERE, "kats_nsfnet320.json"), "w"), separators=(",", ":"))
+    print("kats:", len(cand), "candidate cases,", len(gn), "GN cases")
+
+
+TRAJ = {
+    "traj_nsfnet320": dict(topo_name="nsfnet", seed=1234, load=300, S=320, episodes=3),
+    "traj_nsfnet320_hi": dict(topo_name="nsfnet", seed=77, load=600, S=320, episodes=2,
+                              bit_rates=(10, 40, 100, 400, 1000), launch_power_dbm=1.0),
+    "traj_nobeleu320": dict(topo_name="nobel-eu", seed=5, load=300, S=320, episodes=2),
+    "traj_nsfnet768": dict(topo_name="nsfnet", seed=9, load=600, S=768, episodes=2, episode_length=1500,
+                           snap_steps=(100, 700, 1400)),
+    "traj_cost239": dict(topo_name="cost239", seed=21, load=400, S=320, episodes=2),
+    "traj_nsfnet320_cont": dict(topo_name="nsfnet", seed=3, load=350, S=320, episodes=1, margin=1.5,
+                                launch_power_dbm=-4.0, bit_rate_selection="continuous"),
+    "traj_ring4": dict(topo_name="ring4", seed=11, load=30, S=64, episodes=2, episode_length=300,
+                       snap_steps=(50, 200)),
+    "traj_nsfnet320_scripted": dict(topo_name="nsfnet", seed=4321, load=300, S=320, episodes=1, scripted=True),
+}
+
+
+def main():
+    want = sys.argv[1:]
+    if not want or "tables" in want:
+        for name in ("nsfnet", "nobel-eu", "cost239", "ring4", "germany50"):
+            export_tables(name)
+    if not want or "kats" in want:
+        export_kats()
+    for tag, kw in TRAJ.items():
+        if not want or tag in want:
+            run_trajectory(tag, **kw)
+
+
+if __name__ == "__main__":
+    main()

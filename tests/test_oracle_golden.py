@@ -1,0 +1,140 @@
+"""Pins the CPU restatement (oracle/) against vectors captured from the compiled reference (tests/golden/)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from common import ALL_TRAJ, GOLDEN, golden_tables, holder_for, jocn_modulations, load_traj, traj_requests
+from optical_networking_gym._native import ConfigHolder, F_BLOCKED_OSNR, F_BLOCKED_RESOURCES
+from oracle_lib import OracleEnv
+
+GSNR_RTOL = 1e-12   # same fp64 formula, span-by-span like the reference; libm vs numpy exp differ by ulps
+
+
+@pytest.fixture(scope="module")
+def kats():
+    return json.load(open(os.path.join(GOLDEN, "kats_nsfnet320.json")))
+
+
+@pytest.fixture(scope="module")
+def nsf_env():
+    h = ConfigHolder(golden_tables("nsfnet"), modulations=jocn_modulations(), num_spectrum_resources=320,
+                     load=300, bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400))
+    return OracleEnv(h)
+
+
+def test_candidates(kats, nsf_env):
+    for case in kats["candidates"]:
+        row = np.unpackbits(np.array(case["row"], np.uint8), bitorder="little")[:case["S"]].astype(np.int32)
+        assert nsf_env.candidates(row, case["n"]) == case["starts"]
+
+
+def test_number_slots(kats, nsf_env):
+    for case in kats["number_slots"]:
+        assert [nsf_env.number_slots(case["bit_rate"], m) for m in range(6)] == case["slots"]
+
+
+def test_codec(kats, nsf_env):
+    assert nsf_env.reject_action == kats["constants"]["reject_action"]
+    for case in kats["codec"]:
+        if "decoded" in case:
+            assert nsf_env.decode(case["action"]) == case["decoded"]
+        else:
+            assert nsf_env.encode(*case["encode"]) == case["action"]
+
+
+def test_gn_empty_network(kats, nsf_env):
+    nsf_env.set_trace(traj_requests(load_traj("traj_nsfnet320")[1])[:1])
+    nsf_env.reset()
+    for case in kats["gn_empty"]:
+        out = nsf_env.gn(case["path_id"], case["slot"], case["n"])
+        np.testing.assert_allclose(out, case["out"], rtol=GSNR_RTOL)
+
+
+@pytest.mark.parametrize("tag", ALL_TRAJ + ["traj_nsfnet320_scripted"])
+def test_gn_loaded_network(tag):
+    meta, d = load_traj(tag)
+    env = OracleEnv(holder_for(meta))
+    off = d["gn_linkoff"]
+    cnt_prefix = np.concatenate([[0], np.cumsum(d["gn_cnt"])])
+    for i in range(len(d["gn_path"])):
+        lo, hi = off[i], off[i + 1]
+        counts = d["gn_cnt"][lo:hi]
+        intf = d["gn_intf"][cnt_prefix[lo]:cnt_prefix[hi]]
+        out = env.gn_lists(int(d["gn_path"][i]), int(d["gn_slot"][i]), int(d["gn_n"][i]), counts, intf)
+        np.testing.assert_allclose(out, d["gn_out"][i], rtol=GSNR_RTOL)
+
+
+def replay(tag, policy=True):
+    meta, d = load_traj(tag)
+    env = OracleEnv(holder_for(meta))
+    env.set_trace(traj_requests(d))
+    for _ in range(meta["initial_resets"]):   # constructor reset, explicit reset, episode reset (graph_load.py)
+        env.reset()
+    n = meta["n_steps"]
+    snaps = {int(s): i for i, s in enumerate(d["snap_step"])} if "snap_step" in d else {}
+    ep = 0
+    for i in range(n):
+        act, bres, bosnr = env.policy_first_fit()
+        if policy:
+            assert act == d["st_action"][i], f"step {i}: action {act} != {d['st_action'][i]}"
+            assert bres == bool(d["st_bres"][i]) and bosnr == bool(d["st_bosnr"][i]), f"step {i} flags"
+        else:
+            act = int(d["st_action"][i])
+        rc, r = env.step(act)
+        assert rc == 0
+        assert r["retry"] == d["st_retry"][i], f"step {i} retry"
+        assert r["accepted"] == d["st_accepted"][i], f"step {i} accepted"
+        assert r["reward"] == d["st_reward"][i], f"step {i} reward {r['reward']} {d['st_reward'][i]}"
+        assert r["active"] == d["st_active"][i], f"step {i} active"
+        if not r["retry"]:
+            assert r["route"] == d["st_route"][i] and r["slot"] == d["st_slot"][i]
+            assert r["terminated"] == d["st_term"][i]
+            if r["accepted"]:
+                assert r["modulation"] == d["st_mod"][i] and r["nslots"] == d["st_n"][i]
+                np.testing.assert_allclose([r["osnr"], r["ase"], r["nli"]],
+                                           [d["st_osnr"][i], d["st_ase"][i], d["st_nli"][i]], rtol=GSNR_RTOL)
+            assert env.stats()["episode_services_accepted"] == d["st_ep_acc"][i] or r["terminated"]
+        if i in snaps:
+            grid = np.unpackbits(d["snap_grid"][snaps[i]], axis=1, bitorder="little")[:, :meta["S"]]
+            np.testing.assert_array_equal(env.grid(), grid.astype(np.int32))
+        if r["terminated"]:
+            ti = meta["terminal_infos"][ep]
+            s = env.stats()
+            assert s["last_episode_accepted"] == ti["episode_services_accepted"]
+            assert s["last_rejected"] == ti["rejected"]
+            for k_, f_ in (("service_blocking_rate", "last_service_blocking_rate"),
+                           ("episode_service_blocking_rate", "last_episode_service_blocking_rate"),
+                           ("bit_rate_blocking_rate", "last_bit_rate_blocking_rate"),
+                           ("episode_bit_rate_blocking_rate", "last_episode_bit_rate_blocking_rate")):
+                assert s[f_] == pytest.approx(ti[k_], rel=1e-12, abs=1e-15), k_
+            for m, mod in enumerate(jocn_modulations()):
+                assert s["last_modulation_hist"][m] == ti[f"modulation_{float(mod.spectral_efficiency)}"]
+            assert s["last_mean_gsnr"] == pytest.approx(ti["mean_gsnr"], rel=1e-12)
+            ep += 1
+            env.reset()
+    assert ep == meta["episodes"]
+
+
+@pytest.mark.parametrize("tag", ALL_TRAJ)
+def test_first_fit_trajectory(tag):
+    replay(tag, policy=True)
+
+
+def test_scripted_actions_trajectory():
+    """reject actions and occupied-slot actions (quirk Q5, qrmsa.pyx:886-897) through step(action)."""
+    replay("traj_nsfnet320_scripted", policy=False)
+
+
+def test_request_stream_is_deterministic_and_distributed():
+    meta, _ = load_traj("traj_nsfnet320")
+    h = holder_for(meta)
+    a, b = OracleEnv(h), OracleEnv(h)
+    a.seed(42); b.seed(42)
+    a.reset(); b.reset()
+    ra = a.run_first_fit(400); rb = b.run_first_fit(400)
+    assert ra.tobytes() == rb.tobytes()
+    c = OracleEnv(h, replica=1)
+    c.seed(42); c.reset()
+    assert c.run_first_fit(400).tobytes() != ra.tobytes()
