@@ -1,0 +1,617 @@
+// ongym_device.hpp — device-side data layout and kernels of the batched QRMSA environment (gfx950 / CDNA4).
+//
+// Mapping: ONE WAVEFRONT (64 lanes) PER REPLICA, one 64-thread workgroup each, so there is no inter-wave
+// synchronisation anywhere. A launch loads the replica's mutable state from HBM into LDS once, runs `nsteps` requests
+// against it and writes it back; with nsteps = episode length the state never leaves the CU for a whole episode.
+//
+// Per-replica state in HBM (coalesced: lane i touches word i of a contiguous per-replica block):
+//   occ   u64 [B][E][W]   free-slot bitmap, bit j of word w = slot 64w+j is FREE (the reference keeps int32[E][S] with
+//                         1 = free, envs/qrmsa.pyx:306-309); bits >= S are 0
+//   svc_a u32 [B][C]      running services, unordered: path_id | slot<<16
+//   svc_b u32 [B][C]                                   nslots | modulation<<16
+//   svc_r f32 [B][C]      release time = float32(arrival+holding) (heap key as compared at envs/qrmsa.pyx:1114-1115)
+//   env   DevEnv [B]      clocks, counters, current request, RNG position
+// Constant tables (shared by all replicas, L2/L1 resident): pair->path ids, path->links, path link-masks, GN weights.
+//
+// Wave-uniform bookkeeping (counters, clocks, request draw) is done by lane 0 on the LDS copy of DevEnv; everything
+// that touches the slot grid or the service table is wave-parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ongym.h"
+#include "../../include/ongym_traffic.h"
+
+namespace ongym {
+
+constexpr int kWave = 64;
+constexpr int kMaxMods = 8;
+constexpr int kMaxRowWords = 16;   // n_slots <= 1023 (+1 virtual guard bit)
+constexpr int kMaxLinks = 128;     // two 64-bit link-mask words per path
+constexpr int kMaxHops = 64;       // one lane per hop
+
+enum RunMode { kModePolicyStep = 0, kModeActionStep = 1, kModePolicyOnly = 2 };
+enum ReqMode { kReqNone = 0, kReqRng = 1, kReqTrace = 2 };
+
+struct DevEnv {
+    ongym_stats st;
+    double launch_power, margin, mean_iat;   // per-replica parameters (sweeps as a batch dimension)
+    uint64_t rng_key;
+    uint64_t req_index;                      // requests drawn so far (rng counter / trace cursor)
+    float cur_at, cur_ht, cur_br;            // current_service (C floats in the reference, envs/qrmsa.pyx:35-37)
+    int32_t cur_src, cur_dst, cur_id;
+    int32_t have_request;                    // _new_service (envs/qrmsa.pyx:1077-1078,1102)
+    float min_rel;                           // min release time over running services (+inf if none)
+    int32_t pad0;
+};
+
+struct Params {
+    int n_nodes, n_links, n_paths, k_paths, max_hops, n_mods, n_slots;
+    int row_words;   // W  = ceil(S/64): words per link row in occ
+    int ext_words;   // Wx = S/64 + 1  : words of the row extended by the virtual free slot S
+    int batch, capacity, episode_length, auto_reset;
+    int bit_rate_mode, n_bit_rates, br_lo, br_hi;
+    int uniform_alpha;
+    int req_mode;
+    double f0, slot_bw, channel_width, mean_holding;
+    double alpha0_cl;               // pi^2 |beta2| / (2 alpha) when alpha is uniform
+    // constant tables
+    const int32_t *pair_paths;      // [N*N*K]
+    const int32_t *path_hops;       // [P]
+    const int32_t *path_links;      // [P*max_hops]
+    const uint64_t *path_mask;      // [P*2]  bit e set iff link e on path
+    const double *path_ase;         // [P]    h * sum_l nspans_l (exp(2 a_l L_l) - 1) nf_l
+    const double *link_w1;          // [E]    nspans * l_eff
+    const double *link_w2;          // [E]    nspans * l_eff * l_eff / (L*1e3)
+    const double *link_cl;          // [E]    pi^2 |beta2| * l_eff_a = pi^2 |beta2| / (2 alpha)
+    const double *link_selfc;       // [E]    pi^2 |beta2| / (4 alpha)
+    const double *bit_rates, *bit_rate_cum, *node_cum;
+    int mod_se[kMaxMods];
+    double mod_thr[kMaxMods];
+    double mod_phi53[kMaxMods];     // Phi_mod[se-1] * 5/3  (core/osnr.pyx:38-41,86-92)
+    // mutable state
+    uint64_t *occ;
+    uint32_t *svc_a, *svc_b;
+    float *svc_r;
+    DevEnv *env;
+    // request trace (req_mode == kReqTrace)
+    const ongym_request *trace;
+    long long trace_n;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS carve-up (dynamic shared memory), 8-byte aligned pieces first
+//   occ u64[E*W] | lw1 f64[E] | lw2 f64[E] | lcl f64[E] | lsc f64[E] | DevEnv | sa u32[C] | sb u32[C] | sr f32[C] |
+//   nreq i32[8] | list u16[C]
+// ---------------------------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t lds_bytes(int n_links, int row_words, int capacity) {
+    size_t b = (size_t)n_links * row_words * 8 + (size_t)n_links * 32 + ((sizeof(DevEnv) + 7) & ~(size_t)7);
+    b += (size_t)capacity * 12 + 32 + (size_t)capacity * 2;
+    return (b + 15) & ~(size_t)15;
+}
+
+struct Ctx {
+    const Params &P;
+    int lane;
+    int replica;
+    uint64_t *occ;
+    double *lw1, *lw2, *lcl, *lsc;
+    DevEnv *e;
+    uint32_t *sa, *sb;
+    float *sr;
+    int *nreq;
+    uint16_t *list;
+    int active;        // running services (wave-uniform, mirrored to e->st.active at store time)
+    float min_rel;     // wave-uniform
+    int lane_terms;    // per-lane interferer-link term counter (reduced once per launch)
+    int gn_evals;      // wave-uniform
+    __device__ Ctx(const Params &p) : P(p) {}
+};
+
+__device__ __forceinline__ void ctx_bind(Ctx &c, unsigned char *smem) {
+    const Params &P = c.P;
+    c.occ = reinterpret_cast<uint64_t *>(smem);
+    c.lw1 = reinterpret_cast<double *>(c.occ + (size_t)P.n_links * P.row_words);
+    c.lw2 = c.lw1 + P.n_links;
+    c.lcl = c.lw2 + P.n_links;
+    c.lsc = c.lcl + P.n_links;
+    c.e = reinterpret_cast<DevEnv *>(c.lsc + P.n_links);
+    c.sa = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(c.e) + ((sizeof(DevEnv) + 7) & ~(size_t)7));
+    c.sb = c.sa + P.capacity;
+    c.sr = reinterpret_cast<float *>(c.sb + P.capacity);
+    c.nreq = reinterpret_cast<int *>(c.sr + P.capacity);
+    c.list = reinterpret_cast<uint16_t *>(c.nreq + 8);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// small wave helpers
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uniform_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+__device__ __forceinline__ double uniform_f64(double v) {
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
+    u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+    return u.d;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ uint64_t lanes_below(int lane) { return (1ull << lane) - 1ull; }
+
+// bit s of the result is set iff bits [s, s+m) of the multi-word bitmap are all set. Word w lives in lane w
+// (lanes >= number of words hold 0). Doubling: after a pass the run length covered is r.
+__device__ __forceinline__ uint64_t run_and(uint64_t x, int m) {
+    int r = 1;
+    while (r < m) {
+        int s = min(r, m - r);
+        int q = s >> 6, t = s & 63;
+        uint64_t a = __shfl_down((unsigned long long)x, q);
+        uint64_t b = __shfl_down((unsigned long long)x, q + 1);
+        uint64_t y = t ? ((a >> t) | (b << (64 - t))) : a;
+        x &= y;
+        r += s;
+    }
+    return x;
+}
+
+// lowest set position of a lane-distributed bitmap, or -1
+__device__ __forceinline__ int first_set(uint64_t x) {
+    uint64_t bal = __ballot(x != 0);
+    if (!bal) return -1;
+    int fl = __ffsll((unsigned long long)bal) - 1;
+    uint64_t w = __shfl((unsigned long long)x, fl);
+    return fl * 64 + (__ffsll((unsigned long long)w) - 1);
+}
+
+// mask with bits [lo, hi) of word w set (global slot coordinates)
+__device__ __forceinline__ uint64_t word_range(int w, int lo, int hi) {
+    int a = max(lo - 64 * w, 0), b = min(hi - 64 * w, 64);
+    if (b <= a) return 0;
+    uint64_t m = (b - a == 64) ? ~0ull : ((1ull << (b - a)) - 1ull);
+    return m << a;
+}
+
+// A path as the wave sees it: lane h holds link h.
+struct PathRef {
+    int id, hops;
+    int mylink;          // link index of hop `lane` (undefined for lane >= hops)
+    uint64_t m0, m1;     // link mask
+};
+
+__device__ __forceinline__ PathRef load_path(const Ctx &c, int path) {
+    const Params &P = c.P;
+    PathRef r;
+    r.id = path;
+    r.hops = P.path_hops[path];
+    r.mylink = (c.lane < r.hops) ? P.path_links[path * P.max_hops + c.lane] : 0;
+    r.m0 = P.path_mask[2 * path];
+    r.m1 = P.path_mask[2 * path + 1];
+    return r;
+}
+
+// AND of the free bitmaps of a path's links (get_available_slots, envs/qrmsa.pyx:1482-1512), extended by the virtual
+// free slot S: a run of n+1 set bits starting at s in this bitmap <=> `_get_candidates` accepts s
+// (n slots + right guard, guard waived iff the run ends at S; envs/qrmsa.pyx:515-541, is_path_free :1248-1264).
+__device__ __forceinline__ uint64_t path_free_ext(const Ctx &c, const PathRef &p) {
+    const Params &P = c.P;
+    uint64_t x = (c.lane < P.row_words) ? ~0ull : 0ull;
+    for (int h = 0; h < p.hops; h++) {
+        int l = __shfl(p.mylink, h);
+        if (c.lane < P.row_words) x &= c.occ[l * P.row_words + c.lane];
+    }
+    if (c.lane == (P.n_slots >> 6)) x |= 1ull << (P.n_slots & 63);
+    return x;
+}
+
+// set (free_=true) or clear the slots [lo, hi) on every link of the path; lane h owns link h.
+__device__ __forceinline__ void mark_links(Ctx &c, int hops, int mylink, int lo, int hi, bool free_) {
+    const Params &P = c.P;
+    if (hi > P.n_slots) hi = P.n_slots;
+    if (c.lane < hops && hi > lo) {
+        for (int w = lo >> 6; w <= (hi - 1) >> 6; w++) {
+            uint64_t m = word_range(w, lo, hi);
+            uint64_t v = c.occ[mylink * P.row_words + w];
+            c.occ[mylink * P.row_words + w] = free_ ? (v | m) : (v & ~m);
+        }
+    }
+    __syncthreads();
+}
+
+// ---- GN model (core/osnr.pyx:21-142) ----------------------------------------------------------------------------
+// pass 1: compact the indices of the running services that share >= 1 link with the candidate path.
+__device__ __forceinline__ int gn_build_list(Ctx &c, uint64_t cm0, uint64_t cm1) {
+    const Params &P = c.P;
+    int L = 0;
+    for (int base = 0; base < c.active; base += kWave) {
+        int i = base + c.lane;
+        bool ov = false;
+        if (i < c.active) {
+            int pk = c.sa[i] & 0xFFFF;
+            ov = ((P.path_mask[2 * pk] & cm0) | (P.path_mask[2 * pk + 1] & cm1)) != 0;
+        }
+        uint64_t bal = __ballot(ov);
+        if (ov) c.list[L + __popcll((unsigned long long)(bal & lanes_below(c.lane)))] = (uint16_t)i;
+        L += __popcll((unsigned long long)bal);
+    }
+    __syncthreads();
+    return L;
+}
+
+// asinh(U) - asinh(V), 0 < V < U, as one logarithm
+__device__ __forceinline__ double asinh_diff(double U, double V) {
+    return log((U + sqrt(fma(U, U, 1.0))) / (V + sqrt(fma(V, V, 1.0))));
+}
+
+// pass 2: GSNR/ASE/NLI (dB) of a candidate lightpath (path, slot s, n slots) against the compacted interferers.
+// Span-hoisted: every span of a link is identical (topology.pyx:288-299), so the per-span sums of core/osnr.pyx:50-135
+// collapse to per-link weights w1 = nspans*l_eff, w2 = nspans*l_eff*l_eff/(L*1e3) (quirk Q11).
+template <bool UNIFORM_ALPHA>
+__device__ __forceinline__ void gn_eval(Ctx &c, const PathRef &p, int L, int s, int n, double launch_power,
+                                        double out[3]) {
+    const Params &P = c.P;
+    const double bw = P.slot_bw * n;
+    const int c2 = 2 * s + n;  // candidate centre in half-slots
+    double part = 0.0;
+    // self-channel term asinh(pi^2 |b2| B^2 / (4 alpha)) per link (core/osnr.pyx:58-61), lane h owns link h
+    if (c.lane < p.hops) part = c.lw1[p.mylink] * asinh(c.lsc[p.mylink] * (bw * bw));
+    int terms = 0;
+    for (int j = c.lane; j < L; j += kWave) {
+        int idx = c.list[j];
+        uint32_t a = c.sa[idx], b = c.sb[idx];
+        int pk = a & 0xFFFF, sk = a >> 16, nk = b & 0xFFFF, mk = (b >> 16) & 0xFF;
+        double bk = P.slot_bw * nk;
+        int dfi = (2 * sk + nk) - c2;                      // centre distance in half-slots (exact)
+        double adf = (0.5 * P.slot_bw) * (double)abs(dfi); // |fc_k - fc|
+        double hi = adf + 0.5 * bk, lo = adf - 0.5 * bk;   // lo > 0: allocations never overlap
+        double corr = P.mod_phi53[mk] * (bk / adf);
+        uint64_t m0 = P.path_mask[2 * pk] & p.m0, m1 = P.path_mask[2 * pk + 1] & p.m1;
+        terms += __popcll((unsigned long long)m0) + __popcll((unsigned long long)m1);
+        if (UNIFORM_ALPHA) {
+            double ck = P.alpha0_cl * bk;
+            double A = asinh_diff(ck * hi, ck * lo);
+            double w1 = 0.0, w2 = 0.0;
+            while (m0) { int l = __ffsll((unsigned long long)m0) - 1; m0 &= m0 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
+            while (m1) { int l = 64 + __ffsll((unsigned long long)m1) - 1; m1 &= m1 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
+            part += A * w1 - corr * w2;
+        } else {
+            while (m0 | m1) {
+                int l;
+                if (m0) { l = __ffsll((unsigned long long)m0) - 1; m0 &= m0 - 1; }
+                else { l = 64 + __ffsll((unsigned long long)m1) - 1; m1 &= m1 - 1; }
+                double ck = c.lcl[l] * bk;
+                part += asinh_diff(ck * hi, ck * lo) * c.lw1[l] - corr * c.lw2[l];
+            }
+        }
+    }
+    c.lane_terms += terms;
+    c.gn_evals++;
+    double total = wave_sum(part);
+    const double pi = 3.14159265358979323846, beta2 = 21.3e-27, gamma = 1.3e-3;
+    double ratio = launch_power / bw;
+    double knli = (ratio * ratio * ratio) * (8.0 / (27.0 * pi * beta2)) * (gamma * gamma) * bw;
+    double fc = P.f0 + (P.slot_bw * s) + (P.slot_bw * (n / 2.0));  // envs/qrmsa.pyx:901-905
+    double acc_nli = knli * total / launch_power;
+    double acc_ase = bw * fc * P.path_ase[p.id] / launch_power;
+    out[0] = 10.0 * log10(1.0 / (acc_ase + acc_nli));
+    out[1] = 10.0 * log10(1.0 / acc_ase);
+    out[2] = 10.0 * log10(1.0 / acc_nli);
+}
+
+struct Choice {
+    int action, route, mod, slot, n;
+    int flags;          // ONGYM_F_BLOCKED_*
+    int hops, mylink;   // chosen path as lanes see it
+    double gn[3];
+};
+
+// slots needed per modulation for the current request: get_number_slots (envs/qrmsa.pyx:1198-1205), lane m -> nreq[m]
+__device__ __forceinline__ void fill_number_slots(Ctx &c, float bit_rate) {
+    const Params &P = c.P;
+    if (c.lane < P.n_mods)
+        c.nreq[c.lane] = (int)ceil((double)bit_rate / ((double)P.mod_se[c.lane] * P.channel_width));
+    __syncthreads();
+}
+
+// ---- heuristic_shortest_available_path_first_fit_best_modulation (heuristics/heuristics.py:923-966) -----------
+template <bool UNIFORM_ALPHA>
+__device__ __forceinline__ void policy_first_fit(Ctx &c, int src, int dst, double launch_power, double margin,
+                                                 Choice &ch) {
+    const Params &P = c.P;
+    const int M = P.n_mods, S = P.n_slots, max_mod = M - 1;
+    ch.action = P.k_paths * M * S; ch.route = -1; ch.mod = -1; ch.slot = -1; ch.n = 0; ch.hops = 0; ch.mylink = 0;
+    ch.gn[0] = ch.gn[1] = ch.gn[2] = 0.0;
+    int bres = 0, bosnr = 0;
+    for (int k = 0; k < P.k_paths; k++) {
+        int path = P.pair_paths[(src * P.n_nodes + dst) * P.k_paths + k];
+        if (path < 0) break;
+        PathRef p = load_path(c, path);
+        uint64_t free_ext = path_free_ext(c, p);
+        int L = -1;
+        for (int m = max_mod; m >= 0; m--) {
+            int n = c.nreq[m];
+            if (n <= 0) continue;
+            int first = first_set(run_and(free_ext, n + 1));
+            if (first < 0) { bres = 1; continue; }
+            if (L < 0) L = gn_build_list(c, p.m0, p.m1);
+            double g[3];
+            gn_eval<UNIFORM_ALPHA>(c, p, L, first, n, launch_power, g);
+            int ok = uniform_i32(g[0] >= P.mod_thr[m] + margin);
+            if (ok) {
+                ch.action = k * M * S + (max_mod - m) * S + first;   // get_action_index, heuristics.py:36-54
+                ch.route = k; ch.mod = m; ch.slot = first; ch.n = n; ch.hops = p.hops; ch.mylink = p.mylink;
+                ch.gn[0] = uniform_f64(g[0]); ch.gn[1] = uniform_f64(g[1]); ch.gn[2] = uniform_f64(g[2]);
+                ch.flags = 0;
+                return;
+            }
+            bosnr = 1;
+            bres = 0;
+        }
+    }
+    ch.flags = (bres ? ONGYM_F_BLOCKED_RESOURCES : 0) | (bosnr ? ONGYM_F_BLOCKED_OSNR : 0);
+}
+
+// ---- decode + validate an external action (envs/qrmsa.pyx:801-834, 867-909) ------------------------------------
+// returns 0 accept (GN evaluated, passes), 1 reject action, 2 slots not free (retry), 3 QoT infeasible
+template <bool UNIFORM_ALPHA>
+__device__ __forceinline__ int evaluate_action(Ctx &c, int src, int dst, double launch_power, double margin,
+                                               int action, Choice &ch) {
+    const Params &P = c.P;
+    const int M = P.n_mods, S = P.n_slots, max_mod = M - 1;
+    ch.action = action; ch.route = -1; ch.mod = -1; ch.slot = -1; ch.n = 0; ch.flags = 0; ch.hops = 0; ch.mylink = 0;
+    ch.gn[0] = ch.gn[1] = ch.gn[2] = 0.0;
+    if (action == P.k_paths * M * S) return 1;
+    if (action < 0 || action > P.k_paths * M * S) return 2;
+    int slot = action % S; int t = action / S;
+    int r = t % M; t /= M;
+    int route = t % P.k_paths;
+    int m = max_mod - r;   // allowed_mods = range(max_idx, max_idx-M, -1), max_idx = M-1 when gen_observation=False
+    ch.route = route; ch.mod = m; ch.slot = slot;
+    int path = P.pair_paths[(src * P.n_nodes + dst) * P.k_paths + route];
+    int n = c.nreq[m];
+    ch.n = n;
+    if (path < 0 || n <= 0) return 2;
+    PathRef p = load_path(c, path);
+    ch.hops = p.hops; ch.mylink = p.mylink;
+    uint64_t ok_starts = run_and(path_free_ext(c, p), n + 1);     // is_path_free, envs/qrmsa.pyx:1248-1264
+    uint64_t w = __shfl((unsigned long long)ok_starts, slot >> 6);
+    if (!((w >> (slot & 63)) & 1ull)) return 2;
+    int L = gn_build_list(c, p.m0, p.m1);
+    double g[3];
+    gn_eval<UNIFORM_ALPHA>(c, p, L, slot, n, launch_power, g);
+    ch.gn[0] = uniform_f64(g[0]); ch.gn[1] = uniform_f64(g[1]); ch.gn[2] = uniform_f64(g[2]);
+    return uniform_i32(g[0] >= P.mod_thr[m] + margin) ? 0 : 3;
+}
+
+// ---- departures: release every running service with float32 key <= now (envs/qrmsa.pyx:1113-1122, 1332-1350) ---
+// Set semantics are identical to the heap loop because float32 rounding is monotone. Removal = move the last record
+// into the hole; processing holes from the highest index down keeps every record above the hole a keeper.
+__device__ __forceinline__ void release_due(Ctx &c, float now) {
+    const Params &P = c.P;
+    if (!(c.min_rel <= now)) return;
+    int nchunks = (c.active + kWave - 1) / kWave;
+    for (int ch = nchunks - 1; ch >= 0; ch--) {
+        int i = ch * kWave + c.lane;
+        float r = (i < c.active) ? c.sr[i] : INFINITY;
+        uint64_t bal = __ballot(r <= now);
+        while (bal) {
+            int ln = 63 - __clzll((unsigned long long)bal);
+            bal &= ~(1ull << ln);
+            int idx = ch * kWave + ln;
+            uint32_t a = c.sa[idx], b = c.sb[idx];
+            int pk = a & 0xFFFF, sk = a >> 16, nk = b & 0xFFFF;
+            int hops = P.path_hops[pk];
+            int mylink = (c.lane < hops) ? P.path_links[pk * P.max_hops + c.lane] : 0;
+            mark_links(c, hops, mylink, sk, sk + nk + 1, true);   // frees n+1 slots, clamped at S (quirk Q7)
+            int last = c.active - 1;
+            if (c.lane == 0 && idx != last) { c.sa[idx] = c.sa[last]; c.sb[idx] = c.sb[last]; c.sr[idx] = c.sr[last]; }
+            c.active = last;
+            __syncthreads();
+        }
+    }
+    float mn = INFINITY;
+    for (int base = 0; base < c.active; base += kWave) {
+        int i = base + c.lane;
+        if (i < c.active) mn = fminf(mn, c.sr[i]);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mn = fminf(mn, __shfl_xor(mn, m));
+    c.min_rel = mn;
+}
+
+// ---- _next_service, scalar half (envs/qrmsa.pyx:1067-1111): draw/replay the next request, advance the clock ----
+// Lane 0 only. Returns false if no request could be produced.
+__device__ __forceinline__ bool draw_next(const Params &P, DevEnv *e, int replica) {
+    if (e->have_request) return true;
+    float at, ht, br; int src, dst;
+    if (P.req_mode == kReqRng) {
+        ongym_traffic_params tp = {e->mean_iat, P.mean_holding, P.node_cum, P.n_nodes, P.bit_rate_mode, P.bit_rates,
+                                   P.bit_rate_cum, P.n_bit_rates, P.br_lo, P.br_hi};
+        ongym_drawn_request r = ongym_draw_request(e->rng_key, e->req_index, e->st.current_time, &tp);
+        at = r.arrival_time; ht = r.holding_time; br = r.bit_rate; src = r.source; dst = r.destination;
+    } else if (P.req_mode == kReqTrace && (long long)e->req_index < P.trace_n) {
+        const ongym_request q = P.trace[(long long)replica * P.trace_n + (long long)e->req_index];
+        at = q.arrival_time; ht = q.holding_time; br = q.bit_rate; src = q.source; dst = q.destination;
+    } else {
+        e->st.flags |= ONGYM_F_NO_REQUEST;
+        return false;
+    }
+    e->req_index++;
+    e->st.current_time = (double)at;
+    e->cur_at = at; e->cur_ht = ht; e->cur_br = br; e->cur_src = src; e->cur_dst = dst;
+    e->cur_id = (int32_t)e->st.episode_services_processed;
+    e->have_request = 1;
+    e->st.services_processed += 1;
+    e->st.episode_services_processed += 1;
+    e->st.bit_rate_requested += (double)br;
+    e->st.episode_bit_rate_requested += (double)br;
+    return true;
+}
+
+// ---- reset (envs/qrmsa.pyx:427-504) ----------------------------------------------------------------------------
+__device__ __forceinline__ void reset_env(Ctx &c) {
+    const Params &P = c.P;
+    DevEnv *e = c.e;
+    c.active = 0; c.min_rel = INFINITY;
+    int words = P.n_links * P.row_words;
+    for (int i = c.lane; i < words; i += kWave) c.occ[i] = word_range(i % P.row_words, 0, P.n_slots);
+    if (c.lane == 0) {
+        ongym_stats &s = e->st;
+        s.episode_bit_rate_requested = 0.0; s.episode_bit_rate_provisioned = 0.0;
+        s.episode_services_processed = 0; s.episode_services_accepted = 0;
+        s.rejected = 0;
+        for (int m = 0; m < 8; m++) s.episode_modulation_hist[m] = 0;
+        s.bit_rate_requested = 0.0; s.bit_rate_provisioned = 0.0;   // :466-467
+        s.episode_osnr_sum = 0.0;
+        e->have_request = 0;
+        draw_next(P, e, c.replica);   // no departures possible: the network is empty
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void snapshot_terminal(DevEnv *e) {   // info of the terminal step, envs/qrmsa.pyx:996-1060
+    ongym_stats &s = e->st;
+    s.last_episode_processed = s.episode_services_processed; s.last_episode_accepted = s.episode_services_accepted;
+    s.last_rejected = s.rejected;
+    s.last_service_blocking_rate = s.services_processed > 0
+        ? (double)(s.services_processed - s.services_accepted) / (double)s.services_processed : 0.0;
+    s.last_episode_service_blocking_rate = s.episode_services_processed > 0
+        ? (double)(s.episode_services_processed - s.episode_services_accepted) / (double)s.episode_services_processed : 0.0;
+    s.last_bit_rate_blocking_rate = s.bit_rate_requested > 0
+        ? (s.bit_rate_requested - s.bit_rate_provisioned) / s.bit_rate_requested : 0.0;
+    s.last_episode_bit_rate_blocking_rate = s.episode_bit_rate_requested > 0
+        ? (s.episode_bit_rate_requested - s.episode_bit_rate_provisioned) / s.episode_bit_rate_requested : 0.0;
+    for (int m = 0; m < 8; m++) s.last_modulation_hist[m] = s.episode_modulation_hist[m];
+    // graph_load.py:181-185: mean of Service.OSNR over topology.graph["services"] (one entry per completed step)
+    s.last_mean_gsnr = s.episode_services_processed > 0 ? s.episode_osnr_sum / (double)s.episode_services_processed : 0.0;
+}
+
+// ---- one request: apply the choice (envs/qrmsa.pyx:838-1065) ----------------------------------------------------
+// outcome: 0 = accept & provision, 1 = reject action, 2 = retry (slots busy), 3 = QoT error
+__device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome, ongym_step_rec *rec) {
+    const Params &P = c.P;
+    DevEnv *e = c.e;
+    if (outcome == 2 || outcome == 3) {
+        // slots not free: penalty, same request stays current (quirk Q5, :886-897); QoT error: ValueError (:925-929)
+        if (c.lane == 0 && rec) {
+            ongym_step_rec r;
+            r.action = ch.action; r.route = -1; r.modulation = -1; r.slot = -1; r.nslots = 0;
+            r.accepted = 0; r.terminated = 0; r.retry = 0; r.flags = (uint8_t)ch.flags;
+            r.osnr = 0.0; r.ase = 0.0; r.nli = 0.0; r.reward = 0.0; r.active = c.active;
+            if (outcome == 2) {
+                double failed = (double)(e->st.episode_services_processed - e->st.episode_services_accepted) /
+                                (double)e->st.episode_services_processed;
+                r.reward = -3.0 * (1.0 + failed);   // reward(), :1266-1271
+                r.retry = 1; r.flags |= ONGYM_F_BLOCKED_RESOURCES;
+            } else {
+                r.flags |= ONGYM_F_QOT_ERROR; r.osnr = ch.gn[0]; r.route = (int16_t)ch.route; r.slot = (int16_t)ch.slot;
+            }
+            *rec = r;
+        }
+        return;
+    }
+    int overflow = 0;
+    if (outcome == 0 && c.active >= P.capacity) { outcome = 1; overflow = 1; }
+    float rel = 0.f;
+    if (outcome == 0) {
+        // _provision_path (:1288-1325): occupy n slots + one guard slot unless the allocation ends at S
+        int end = ch.slot + ch.n; if (end < P.n_slots) end += 1;
+        mark_links(c, ch.hops, ch.mylink, ch.slot, end, false);
+    }
+    if (c.lane == 0) {
+        ongym_stats &s = e->st;
+        ongym_step_rec r;
+        r.action = ch.action; r.route = -1; r.modulation = -1; r.slot = -1; r.nslots = 0;
+        r.accepted = 0; r.terminated = 0; r.retry = 0; r.flags = (uint8_t)ch.flags;
+        r.osnr = 0.0; r.ase = 0.0; r.nli = 0.0; r.reward = 0.0; r.active = 0;
+        double osnr = 0.0;
+        if (outcome == 0) {
+            int path = P.pair_paths[(e->cur_src * P.n_nodes + e->cur_dst) * P.k_paths + ch.route];
+            rel = e->cur_at + e->cur_ht;   // float + float (:1329); compared as float32 (:1114-1115)
+            c.sa[c.active] = (uint32_t)path | ((uint32_t)ch.slot << 16);
+            c.sb[c.active] = (uint32_t)ch.n | ((uint32_t)ch.mod << 16);
+            c.sr[c.active] = rel;
+            s.services_accepted += 1; s.episode_services_accepted += 1;
+            s.bit_rate_provisioned += (double)e->cur_br;
+            s.episode_bit_rate_provisioned =
+                (double)(int64_t)(s.episode_bit_rate_provisioned + (double)e->cur_br);   // :1319-1321
+            s.episode_modulation_hist[ch.mod] += 1;
+            s.total_accepted += 1;
+            r.accepted = 1; r.route = (int16_t)ch.route; r.modulation = (int16_t)ch.mod; r.slot = (int16_t)ch.slot;
+            r.nslots = (int16_t)ch.n; r.osnr = ch.gn[0]; r.ase = ch.gn[1]; r.nli = ch.gn[2];
+            osnr = ch.gn[0];
+            r.reward = 0.0;                       // reward() falls off the end when accepted (quirk Q1)
+        } else {
+            s.rejected += 1;                      // bl_reject (:865)
+            r.reward = -6.0;                      // :992-995
+            if (overflow) { r.flags |= ONGYM_F_OVERFLOW; s.flags |= ONGYM_F_OVERFLOW; }
+        }
+        s.episode_osnr_sum += osnr;
+        s.total_steps += 1;
+        e->have_request = 0;
+        if (s.episode_services_processed + 1 == P.episode_length) snapshot_terminal(e);
+        draw_next(P, e, c.replica);
+        r.terminated = (uint8_t)(s.episode_services_processed == P.episode_length);
+        if (r.terminated) s.episodes_completed += 1;
+        if (rec) *rec = r;
+    }
+    if (outcome == 0) {
+        rel = uniform_f32(rel);
+        c.active++;
+        c.min_rel = fminf(c.min_rel, rel);
+    }
+    __syncthreads();
+    release_due(c, e->cur_at);                    // second half of _next_service (:1113-1122)
+    if (rec && c.lane == 0) rec->active = c.active;
+    int terminated = e->st.episode_services_processed == P.episode_length;
+    if (terminated && P.auto_reset) reset_env(c);
+}
+
+__device__ __forceinline__ void load_state(Ctx &c) {
+    const Params &P = c.P;
+    // DevEnv: 8-byte words by lanes
+    const uint64_t *ge = reinterpret_cast<const uint64_t *>(P.env + c.replica);
+    uint64_t *le = reinterpret_cast<uint64_t *>(c.e);
+    for (int i = c.lane; i < (int)(sizeof(DevEnv) / 8); i += kWave) le[i] = ge[i];
+    for (int i = c.lane; i < P.n_links; i += kWave) {
+        c.lw1[i] = P.link_w1[i]; c.lw2[i] = P.link_w2[i]; c.lcl[i] = P.link_cl[i]; c.lsc[i] = P.link_selfc[i];
+    }
+    int words = P.n_links * P.row_words;
+    const uint64_t *g = P.occ + (size_t)c.replica * words;
+    for (int i = c.lane; i < words; i += kWave) c.occ[i] = g[i];
+    __syncthreads();
+    c.active = c.e->st.active;
+    c.min_rel = c.e->min_rel;
+    size_t off = (size_t)c.replica * P.capacity;
+    for (int i = c.lane; i < c.active; i += kWave) { c.sa[i] = P.svc_a[off + i]; c.sb[i] = P.svc_b[off + i]; c.sr[i] = P.svc_r[off + i]; }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void store_state(Ctx &c) {
+    const Params &P = c.P;
+    int terms = c.lane_terms;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) terms += __shfl_xor(terms, m);
+    if (c.lane == 0) {
+        c.e->st.active = c.active;
+        c.e->min_rel = c.min_rel;
+        c.e->st.total_gn_evals += c.gn_evals;
+        c.e->st.total_interferer_terms += terms;
+    }
+    __syncthreads();
+    uint64_t *ge = reinterpret_cast<uint64_t *>(P.env + c.replica);
+    const uint64_t *le = reinterpret_cast<const uint64_t *>(c.e);
+    for (int i = c.lane; i < (int)(sizeof(DevEnv) / 8); i += kWave) ge[i] = le[i];
+    int words = P.n_links * P.row_words;
+    uint64_t *g = P.occ + (size_t)c.replica * words;
+    for (int i = c.lane; i < words; i += kWave) g[i] = c.occ[i];
+    size_t off = (size_t)c.replica * P.capacity;
+    for (int i = c.lane; i < c.active; i += kWave) { P.svc_a[off + i] = c.sa[i]; P.svc_b[off + i] = c.sb[i]; P.svc_r[off + i] = c.sr[i]; }
+}
+
+}  // namespace ongym

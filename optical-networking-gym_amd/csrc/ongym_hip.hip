@@ -1,0 +1,613 @@
+// ongym_hip.hip — kernels + C ABI (include/ongym.h) of the MI355X-native batched QRMSA environment.
+// Build: hipcc --offload-arch=gfx950 -O3 -fPIC -shared -o libongym_hip.so ongym_hip.hip   (see __graft_entry__.build)
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ongym_device.hpp"
+
+using namespace ongym;
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------------------
+template <bool UA>
+__global__ __launch_bounds__(64) void k_run(Params P, int mode, int nsteps, const int32_t *actions, int32_t *act_out,
+                                            uint8_t *flag_out, ongym_step_rec *out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    Ctx c(P);
+    c.lane = threadIdx.x;
+    c.replica = blockIdx.x;
+    c.lane_terms = 0;
+    c.gn_evals = 0;
+    ctx_bind(c, smem);
+    load_state(c);
+    for (int it = 0; it < nsteps; ++it) {
+        DevEnv *e = c.e;
+        ongym_step_rec *rec = out ? out + (size_t)it * P.batch + c.replica : nullptr;
+        if (!e->have_request) {   // no request source / trace exhausted: the step is a no-op
+            if (c.lane == 0) {
+                e->st.flags |= ONGYM_F_NO_REQUEST;
+                if (rec) { memset(rec, 0, sizeof(*rec)); rec->action = -1; rec->route = rec->modulation = rec->slot = -1;
+                           rec->flags = ONGYM_F_NO_REQUEST; rec->active = c.active; }
+                if (mode == kModePolicyOnly) { act_out[c.replica] = -1; if (flag_out) flag_out[c.replica] = ONGYM_F_NO_REQUEST; }
+            }
+            __syncthreads();
+            continue;
+        }
+        int src = e->cur_src, dst = e->cur_dst;
+        float br = e->cur_br;
+        double lp = e->launch_power, mg = e->margin;
+        fill_number_slots(c, br);
+        Choice ch;
+        int outcome;
+        if (mode == kModeActionStep) {
+            outcome = evaluate_action<UA>(c, src, dst, lp, mg, actions[c.replica], ch);
+        } else {
+            policy_first_fit<UA>(c, src, dst, lp, mg, ch);
+            outcome = ch.route >= 0 ? 0 : 1;
+        }
+        if (mode == kModePolicyOnly) {
+            if (c.lane == 0) { act_out[c.replica] = ch.action; if (flag_out) flag_out[c.replica] = (uint8_t)ch.flags; }
+            continue;
+        }
+        apply_step(c, ch, outcome, rec);
+    }
+    if (mode != kModePolicyOnly) store_state(c);
+}
+
+__global__ __launch_bounds__(64) void k_reset(Params P, const uint8_t *mask) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (mask && !mask[blockIdx.x]) return;
+    Ctx c(P);
+    c.lane = threadIdx.x;
+    c.replica = blockIdx.x;
+    c.lane_terms = 0;
+    c.gn_evals = 0;
+    ctx_bind(c, smem);
+    load_state(c);
+    reset_env(c);
+    store_state(c);
+}
+
+__global__ void k_seed(Params P, uint64_t seed) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= P.batch) return;
+    P.env[r].rng_key = ongym_stream_key(seed, (uint64_t)r);
+    P.env[r].req_index = 0;
+}
+
+__global__ void k_rewind(Params P) {   // new trace: cursor back to 0
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= P.batch) return;
+    P.env[r].req_index = 0;
+}
+
+enum { kQAvailable = 0, kQGsnr = 1, kQGrid = 2, kQServices = 3, kQRequest = 4 };
+
+template <bool UA>
+__global__ __launch_bounds__(64) void k_query(Params P, int what, int replica, int path, int slot, int n,
+                                              int32_t *out_i, double *out_d) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    Ctx c(P);
+    c.lane = threadIdx.x;
+    c.replica = replica;
+    c.lane_terms = 0;
+    c.gn_evals = 0;
+    ctx_bind(c, smem);
+    load_state(c);
+    if (what == kQAvailable) {          // get_available_slots(path), envs/qrmsa.pyx:1482-1512
+        PathRef p = load_path(c, path);
+        uint64_t x = path_free_ext(c, p);
+        for (int j = 0; j < P.n_slots; j++) {
+            uint64_t w = __shfl((unsigned long long)x, j >> 6);
+            if (c.lane == 0) out_i[j] = (int32_t)((w >> (j & 63)) & 1ull);
+        }
+    } else if (what == kQGsnr) {        // calculate_osnr(env, candidate), core/osnr.pyx:21-142
+        PathRef p = load_path(c, path);
+        int L = gn_build_list(c, p.m0, p.m1);
+        double g[3];
+        gn_eval<UA>(c, p, L, slot, n, c.e->launch_power, g);
+        if (c.lane == 0) { out_d[0] = g[0]; out_d[1] = g[1]; out_d[2] = g[2]; }
+    } else if (what == kQGrid) {        // topology.graph["available_slots"]
+        for (int i = c.lane; i < P.n_links * P.n_slots; i += kWave) {
+            int l = i / P.n_slots, j = i % P.n_slots;
+            out_i[i] = (int32_t)((c.occ[l * P.row_words + (j >> 6)] >> (j & 63)) & 1ull);
+        }
+    } else if (what == kQServices) {    // running services
+        ongym_service *o = reinterpret_cast<ongym_service *>(out_i + 2);
+        if (c.lane == 0) out_i[0] = c.active;
+        for (int i = c.lane; i < c.active; i += kWave) {
+            uint32_t a = c.sa[i], b = c.sb[i];
+            o[i].path_id = a & 0xFFFF; o[i].slot = (int16_t)(a >> 16); o[i].nslots = (int16_t)(b & 0xFFFF);
+            o[i].modulation = (int16_t)((b >> 16) & 0xFF); o[i].reserved = 0; o[i].release_time = c.sr[i];
+        }
+    } else if (what == kQRequest) {
+        if (c.lane == 0) {
+            ongym_request *q = reinterpret_cast<ongym_request *>(out_i);
+            q->arrival_time = c.e->cur_at; q->holding_time = c.e->cur_ht; q->bit_rate = c.e->cur_br;
+            q->source = (int16_t)c.e->cur_src; q->destination = (int16_t)c.e->cur_dst;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+struct ongym_env {
+    ongym_config cfg{};
+    Params P{};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    size_t lds = 0;
+    std::vector<void *> allocs;
+    std::string err;
+    void *d_trace = nullptr;        // owned copy of a host trace
+    ongym_step_rec *d_out = nullptr; size_t d_out_n = 0;
+    int32_t *d_actions = nullptr; int32_t *d_act_out = nullptr; uint8_t *d_flag_out = nullptr; uint8_t *d_mask = nullptr;
+    int32_t *d_scratch_i = nullptr; size_t scratch_i_bytes = 0; double *d_scratch_d = nullptr;
+    bool has_source = false;
+};
+
+#define HIP_TRY(env, expr)                                                                               \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess) {                                                                          \
+            (env)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                              \
+            return ONGYM_E_HIP;                                                                          \
+        }                                                                                                \
+    } while (0)
+
+static std::string g_create_error;
+
+template <typename T>
+static int upload(ongym_env *env, const T *src, size_t n, const T **dst) {
+    void *d = nullptr;
+    HIP_TRY(env, hipMalloc(&d, n ? n * sizeof(T) : sizeof(T)));
+    env->allocs.push_back(d);
+    if (n) HIP_TRY(env, hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice));
+    *dst = static_cast<const T *>(d);
+    return 0;
+}
+
+template <typename T>
+static int dev_alloc(ongym_env *env, size_t n, T **dst, bool zero) {
+    void *d = nullptr;
+    HIP_TRY(env, hipMalloc(&d, n ? n * sizeof(T) : sizeof(T)));
+    env->allocs.push_back(d);
+    if (zero && n) HIP_TRY(env, hipMemset(d, 0, n * sizeof(T)));
+    *dst = static_cast<T *>(d);
+    return 0;
+}
+
+static int fail_arg(ongym_env *env, const char *msg, int code = ONGYM_E_ARG) {
+    env->err = msg;
+    return code;
+}
+
+static int build(ongym_env *env, const ongym_config *c) {
+    Params &P = env->P;
+    if (c->n_nodes <= 1 || c->n_links <= 0 || c->n_paths <= 0 || c->k_paths <= 0 || c->max_hops <= 0 ||
+        c->n_mods <= 0 || c->n_slots <= 0 || c->batch <= 0 || c->episode_length <= 1)
+        return fail_arg(env, "non-positive size in ongym_config");
+    if (c->n_mods > kMaxMods) return fail_arg(env, "n_mods > 8", ONGYM_E_LIMIT);
+    if (c->n_links > kMaxLinks) return fail_arg(env, "n_links > 128", ONGYM_E_LIMIT);
+    if (c->max_hops > kMaxHops) return fail_arg(env, "max_hops > 64", ONGYM_E_LIMIT);
+    if (c->n_slots > 1023) return fail_arg(env, "n_slots > 1023", ONGYM_E_LIMIT);
+    if (c->n_paths > 65535) return fail_arg(env, "n_paths > 65535", ONGYM_E_LIMIT);
+    if (c->capacity <= 0 || c->capacity % 64 || c->capacity > 65535)
+        return fail_arg(env, "capacity must be a multiple of 64 in (0, 65535)");
+    if (!c->pair_paths || !c->path_hops || !c->path_links || !c->link_nspans || !c->link_span_km || !c->link_alpha ||
+        !c->link_nf || !c->mod_se || !c->mod_min_osnr || !c->node_cum)
+        return fail_arg(env, "null table pointer in ongym_config");
+    if (c->bit_rate_mode == 0 && (!c->bit_rates || !c->bit_rate_cum || c->n_bit_rates <= 0))
+        return fail_arg(env, "discrete bit-rate mode needs bit_rates/bit_rate_cum");
+    if (c->load <= 0 || c->mean_holding_time <= 0) return fail_arg(env, "load and mean_holding_time must be positive");
+
+    const int N = c->n_nodes, E = c->n_links, NP = c->n_paths, K = c->k_paths, H = c->max_hops, M = c->n_mods;
+    // validate tables on the host before any kernel indexes with them
+    for (int i = 0; i < N * N * K; i++)
+        if (c->pair_paths[i] < -1 || c->pair_paths[i] >= NP) return fail_arg(env, "pair_paths entry out of range");
+    for (int p = 0; p < NP; p++) {
+        if (c->path_hops[p] <= 0 || c->path_hops[p] > H) return fail_arg(env, "path_hops entry out of range");
+        for (int h = 0; h < c->path_hops[p]; h++)
+            if (c->path_links[p * H + h] < 0 || c->path_links[p * H + h] >= E)
+                return fail_arg(env, "path_links entry out of range");
+    }
+    for (int m = 0; m < M; m++)
+        if (c->mod_se[m] < 1 || c->mod_se[m] > 6) return fail_arg(env, "spectral efficiency must be 1..6");
+    for (int e = 0; e < E; e++)
+        if (!(c->link_alpha[e] > 0) || !(c->link_span_km[e] > 0) || c->link_nspans[e] <= 0)
+            return fail_arg(env, "link span parameters must be positive");
+
+    P.n_nodes = N; P.n_links = E; P.n_paths = NP; P.k_paths = K; P.max_hops = H; P.n_mods = M; P.n_slots = c->n_slots;
+    P.row_words = (c->n_slots + 63) / 64;
+    P.ext_words = c->n_slots / 64 + 1;
+    P.batch = c->batch; P.capacity = c->capacity; P.episode_length = c->episode_length; P.auto_reset = c->auto_reset;
+    P.bit_rate_mode = c->bit_rate_mode; P.n_bit_rates = c->n_bit_rates; P.br_lo = c->bit_rate_lo; P.br_hi = c->bit_rate_hi;
+    P.req_mode = kReqNone;
+    P.f0 = c->frequency_start; P.slot_bw = c->slot_bandwidth; P.channel_width = c->channel_width;
+    P.mean_holding = c->mean_holding_time;
+
+    // derived GN tables in fp64 (core/osnr.pyx:22-24, 52-55, 58-61, 109-125)
+    const double pi = 3.14159265358979323846, beta2 = 21.3e-27, h_planck = 6.626e-34;
+    std::vector<double> w1(E), w2(E), cl(E), selfc(E), ase_link(E);
+    bool uniform = true;
+    for (int e = 0; e < E; e++) {
+        double a = c->link_alpha[e], L = c->link_span_km[e];
+        double l_eff = (1.0 - std::exp(-2.0 * a * L * 1e3)) / (2.0 * a);
+        w1[e] = (double)c->link_nspans[e] * l_eff;
+        w2[e] = (double)c->link_nspans[e] * l_eff * (l_eff / (L * 1e3));
+        cl[e] = pi * pi * beta2 * (1.0 / (2.0 * a));
+        selfc[e] = pi * pi * beta2 / (4.0 * a);
+        ase_link[e] = (double)c->link_nspans[e] * h_planck * (std::exp(2.0 * a * L * 1e3) - 1.0) * c->link_nf[e];
+        if (a != c->link_alpha[0]) uniform = false;
+    }
+    P.uniform_alpha = uniform ? 1 : 0;
+    P.alpha0_cl = cl[0];
+    std::vector<uint64_t> mask((size_t)NP * 2, 0);
+    std::vector<double> path_ase(NP, 0.0);
+    for (int p = 0; p < NP; p++)
+        for (int h = 0; h < c->path_hops[p]; h++) {
+            int l = c->path_links[p * H + h];
+            mask[2 * p + (l >> 6)] |= 1ull << (l & 63);
+            path_ase[p] += ase_link[l];
+        }
+    static const double phi_mod[6] = {1.0, 1.0, 2.0 / 3.0, 17.0 / 25.0, 69.0 / 100.0, 13.0 / 21.0};
+    for (int m = 0; m < M; m++) {
+        P.mod_se[m] = c->mod_se[m];
+        P.mod_thr[m] = c->mod_min_osnr[m];
+        P.mod_phi53[m] = phi_mod[c->mod_se[m] - 1] * (5.0 / 3.0);
+    }
+    int rc;
+    if ((rc = upload(env, c->pair_paths, (size_t)N * N * K, &P.pair_paths))) return rc;
+    if ((rc = upload(env, c->path_hops, (size_t)NP, &P.path_hops))) return rc;
+    if ((rc = upload(env, c->path_links, (size_t)NP * H, &P.path_links))) return rc;
+    if ((rc = upload(env, mask.data(), mask.size(), &P.path_mask))) return rc;
+    if ((rc = upload(env, path_ase.data(), path_ase.size(), &P.path_ase))) return rc;
+    if ((rc = upload(env, w1.data(), w1.size(), &P.link_w1))) return rc;
+    if ((rc = upload(env, w2.data(), w2.size(), &P.link_w2))) return rc;
+    if ((rc = upload(env, cl.data(), cl.size(), &P.link_cl))) return rc;
+    if ((rc = upload(env, selfc.data(), selfc.size(), &P.link_selfc))) return rc;
+    double one = 1.0, zero = 0.0;
+    if ((rc = upload(env, c->bit_rate_mode == 0 ? c->bit_rates : &zero, c->bit_rate_mode == 0 ? (size_t)c->n_bit_rates : 1, &P.bit_rates))) return rc;
+    if ((rc = upload(env, c->bit_rate_mode == 0 ? c->bit_rate_cum : &one, c->bit_rate_mode == 0 ? (size_t)c->n_bit_rates : 1, &P.bit_rate_cum))) return rc;
+    if (c->bit_rate_mode != 0) P.n_bit_rates = 1;
+    if ((rc = upload(env, c->node_cum, (size_t)N, &P.node_cum))) return rc;
+
+    // mutable state
+    const size_t B = (size_t)c->batch;
+    if ((rc = dev_alloc(env, B * E * P.row_words, &P.occ, true))) return rc;
+    if ((rc = dev_alloc(env, B * c->capacity, &P.svc_a, true))) return rc;
+    if ((rc = dev_alloc(env, B * c->capacity, &P.svc_b, true))) return rc;
+    if ((rc = dev_alloc(env, B * c->capacity, &P.svc_r, true))) return rc;
+    if ((rc = dev_alloc(env, B, &P.env, false))) return rc;
+    std::vector<DevEnv> host(B);
+    memset(host.data(), 0, B * sizeof(DevEnv));
+    for (size_t r = 0; r < B; r++) {
+        DevEnv &d = host[r];
+        d.launch_power = c->replica_launch_power_w ? c->replica_launch_power_w[r] : c->launch_power_w;
+        d.margin = c->replica_margin ? c->replica_margin[r] : c->margin;
+        double load = c->replica_load ? c->replica_load[r] : c->load;
+        if (!(load > 0) || !(d.launch_power > 0)) return fail_arg(env, "per-replica load / launch power must be positive");
+        d.mean_iat = 1 / (load / c->mean_holding_time);   // set_load, envs/qrmsa.pyx:1124-1132
+        d.min_rel = INFINITY;
+    }
+    HIP_TRY(env, hipMemcpy(P.env, host.data(), B * sizeof(DevEnv), hipMemcpyHostToDevice));
+    // the bitmaps start "all free" so that queries before the first reset see an empty network
+    {
+        std::vector<uint64_t> row(P.row_words);
+        for (int w = 0; w < P.row_words; w++) {
+            int a = 0, b = std::min(c->n_slots - 64 * w, 64);
+            row[w] = b >= 64 ? ~0ull : ((1ull << b) - 1ull);
+            (void)a;
+        }
+        std::vector<uint64_t> all(B * E * P.row_words);
+        for (size_t i = 0; i < all.size(); i++) all[i] = row[i % P.row_words];
+        HIP_TRY(env, hipMemcpy(P.occ, all.data(), all.size() * 8, hipMemcpyHostToDevice));
+    }
+    env->lds = lds_bytes(E, P.row_words, c->capacity);
+    if (env->lds > 64 * 1024) {
+        if (env->lds > 160 * 1024) return fail_arg(env, "state does not fit the 160 KiB LDS: lower capacity", ONGYM_E_LIMIT);
+        HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_run<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->lds));
+        HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_run<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->lds));
+        HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_reset), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->lds));
+        HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_query<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->lds));
+        HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_query<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->lds));
+    }
+    // scratch for queries / host-buffer I/O
+    env->scratch_i_bytes = std::max((size_t)E * c->n_slots * 4, (size_t)c->capacity * sizeof(ongym_service) + 16);
+    if ((rc = dev_alloc(env, env->scratch_i_bytes / 4 + 4, &env->d_scratch_i, true))) return rc;
+    if ((rc = dev_alloc(env, 4, &env->d_scratch_d, true))) return rc;
+    if ((rc = dev_alloc(env, B, &env->d_actions, true))) return rc;
+    if ((rc = dev_alloc(env, B, &env->d_act_out, true))) return rc;
+    if ((rc = dev_alloc(env, B, &env->d_flag_out, true))) return rc;
+    if ((rc = dev_alloc(env, B, &env->d_mask, true))) return rc;
+    return 0;
+}
+
+extern "C" {
+
+int32_t ongym_abi_version(void) { return ONGYM_ABI_VERSION; }
+
+int32_t ongym_sizeof(int32_t what) {
+    switch (what) {
+        case 0: return (int32_t)sizeof(ongym_config);
+        case 1: return (int32_t)sizeof(ongym_request);
+        case 2: return (int32_t)sizeof(ongym_step_rec);
+        case 3: return (int32_t)sizeof(ongym_service);
+        case 4: return (int32_t)sizeof(ongym_stats);
+        default: return -1;
+    }
+}
+
+const char *ongym_last_error(ongym_env *env) { return env ? env->err.c_str() : g_create_error.c_str(); }
+
+int ongym_create(const ongym_config *cfg, ongym_env **out) {
+    if (!cfg || !out) { g_create_error = "null argument"; return ONGYM_E_ARG; }
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(ongym_config) || cfg->abi_version != ONGYM_ABI_VERSION) {
+        g_create_error = "ongym_config struct_size / abi_version mismatch";
+        return ONGYM_E_ARG;
+    }
+    ongym_env *env = new (std::nothrow) ongym_env();
+    if (!env) { g_create_error = "out of memory"; return ONGYM_E_ARG; }
+    env->cfg = *cfg;
+    int ndev = 0;
+    hipError_t he = hipGetDeviceCount(&ndev);
+    if (he != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+        g_create_error = "no usable HIP device (hipGetDeviceCount: " + std::string(hipGetErrorString(he)) + ")";
+        delete env;
+        return ONGYM_E_HIP;
+    }
+    int rc = 0;
+    do {
+        if (hipSetDevice(cfg->device) != hipSuccess) { env->err = "hipSetDevice failed"; rc = ONGYM_E_HIP; break; }
+        if (hipStreamCreateWithFlags(&env->stream, hipStreamNonBlocking) != hipSuccess) { env->err = "hipStreamCreate failed"; rc = ONGYM_E_HIP; break; }
+        if (hipEventCreate(&env->ev0) != hipSuccess || hipEventCreate(&env->ev1) != hipSuccess) { env->err = "hipEventCreate failed"; rc = ONGYM_E_HIP; break; }
+        rc = build(env, cfg);
+    } while (0);
+    if (rc) {
+        g_create_error = env->err;
+        ongym_destroy(env);
+        return rc;
+    }
+    *out = env;
+    return ONGYM_OK;
+}
+
+void ongym_destroy(ongym_env *env) {
+    if (!env) return;
+    hipSetDevice(env->cfg.device);
+    if (env->stream) hipStreamSynchronize(env->stream);
+    for (void *p : env->allocs) hipFree(p);
+    if (env->d_trace) hipFree(env->d_trace);
+    if (env->d_out) hipFree(env->d_out);
+    if (env->ev0) hipEventDestroy(env->ev0);
+    if (env->ev1) hipEventDestroy(env->ev1);
+    if (env->stream) hipStreamDestroy(env->stream);
+    delete env;
+}
+
+int ongym_sync(ongym_env *env) {
+    if (!env) return ONGYM_E_ARG;
+    HIP_TRY(env, hipSetDevice(env->cfg.device));
+    HIP_TRY(env, hipStreamSynchronize(env->stream));
+    return ONGYM_OK;
+}
+
+double ongym_last_kernel_ms(ongym_env *env) {
+    if (!env || !env->timed) return -1.0;
+    if (hipEventSynchronize(env->ev1) != hipSuccess) return -1.0;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, env->ev0, env->ev1) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+int ongym_seed(ongym_env *env, uint64_t seed) {
+    if (!env) return ONGYM_E_ARG;
+    HIP_TRY(env, hipSetDevice(env->cfg.device));
+    env->P.req_mode = kReqRng;
+    env->has_source = true;
+    int threads = 256, blocks = (env->P.batch + threads - 1) / threads;
+    hipLaunchKernelGGL(k_seed, dim3(blocks), dim3(threads), 0, env->stream, env->P, seed);
+    HIP_TRY(env, hipGetLastError());
+    return ONGYM_OK;
+}
+
+int ongym_set_requests(ongym_env *env, const ongym_request *reqs, int64_t n_per_replica) {
+    if (!env || !reqs || n_per_replica <= 0) return env ? fail_arg(env, "bad trace") : ONGYM_E_ARG;
+    HIP_TRY(env, hipSetDevice(env->cfg.device));
+    HIP_TRY(env, hipStreamSynchronize(env->stream));
+    size_t n = (size_t)env->P.batch * (size_t)n_per_replica;
+    // validate node indices on the host when the trace is a host buffer (device traces are the caller's contract)
+    if (!env->cfg.io_device) {
+        for (size_t i = 0; i < n; i++) {
+            const ongym_request &q = reqs[i];
+            if (q.source < 0 || q.source >= env->P.n_nodes || q.destination < 0 || q.destination >= env->P.n_nodes ||
+                q.source == q.destination || !(q.bit_rate > 0))
+                return fail_arg(env, "trace entry with invalid node pair / bit rate");
+        }
+        if (env->d_trace) { hipFree(env->d_trace); env->d_trace = nullptr; }
+        HIP_TRY(env, hipMalloc(&env->d_trace, n * sizeof(ongym_request)));
+        HIP_TRY(env, hipMemcpy(env->d_trace, reqs, n * sizeof(ongym_request), hipMemcpyHostToDevice));
+        env->P.trace = static_cast<const ongym_request *>(env->d_trace);
+    } else {
+        env->P.trace = reqs;
+    }
+    env->P.trace_n = n_per_replica;
+    env->P.req_mode = kReqTrace;
+    env->has_source = true;
+    int threads = 256, blocks = (env->P.batch + threads - 1) / threads;
+    hipLaunchKernelGGL(k_rewind, dim3(blocks), dim3(threads), 0, env->stream, env->P);
+    HIP_TRY(env, hipGetLastError());
+    return ONGYM_OK;
+}
+
+int ongym_reset(ongym_env *env, const uint8_t *mask) {
+    if (!env) return ONGYM_E_ARG;
+    if (!env->has_source) { env->err = "no request source: call ongym_seed or ongym_set_requests first"; return ONGYM_E_STATE; }
+    HIP_TRY(env, hipSetDevice(env->cfg.device));
+    const uint8_t *dmask = nullptr;
+    if (mask) {
+        if (env->cfg.io_device) dmask = mask;
+        else {
+            HIP_TRY(env, hipMemcpyAsync(env->d_mask, mask, (size_t)env->P.batch, hipMemcpyHostToDevice, env->stream));
+            dmask = env->d_mask;
+        }
+    }
+    hipLaunchKernelGGL(k_reset, dim3(env->P.batch), dim3(64), env->lds, env->stream, env->P, dmask);
+    HIP_TRY(env, hipGetLastError());
+    return ONGYM_OK;
+}
+
+static int launch_run(ongym_env *env, int mode, int nsteps, const int32_t *d_actions, int32_t *d_act_out,
+                      uint8_t *d_flag_out, ongym_step_rec *d_out) {
+    HIP_TRY(env, hipEventRecord(env->ev0, env->stream));
+    if (env->P.uniform_alpha)
+        hipLaunchKernelGGL(k_run<true>, dim3(env->P.batch), dim3(64), env->lds, env->stream, env->P, mode, nsteps,
+                           d_actions, d_act_out, d_flag_out, d_out);
+    else
+        hipLaunchKernelGGL(k_run<false>, dim3(env->P.batch), dim3(64), env->lds, env->stream, env->P, mode, nsteps,
+                           d_actions, d_act_out, d_flag_out, d_out);
+    HIP_TRY(env, hipGetLastError());
+    HIP_TRY(env, hipEventRecord(env->ev1, env->stream));
+    env->timed = true;
+    return 0;
+}
+
+static int ensure_out(ongym_env *env, size_t n) {
+    if (env->d_out_n >= n) return 0;
+    if (env->d_out) { hipFree(env->d_out); env->d_out = nullptr; env->d_out_n = 0; }
+    HIP_TRY(env, hipMalloc(reinterpret_cast<void **>(&env->d_out), n * sizeof(ongym_step_rec)));
+    env->d_out_n = n;
+    return 0;
+}
+
+int ongym_step_policy(ongym_env *env, int32_t policy, int32_t nsteps, ongym_step_rec *out) {
+    if (!env) return ONGYM_E_ARG;
+    if (policy != ONGYM_POLICY_FIRST_FIT) return fail_arg(env, "unknown policy id");
+    if (nsteps <= 0) return fail_arg(env, "nsteps must be positive");
+    if (!env->has_source) { env->err = "no request source: call ongym_seed or ongym_set_requests first"; return ONGYM_E_STATE; }
+    HIP_TRY(env, hipSetDevice(env->cfg.device));
+    int rc;
+    if (out && !env->cfg.io_device) {
+        size_t n = (size_t)nsteps * env->P.batch;
+        if ((rc = ensure_out(env, n))) return rc;
+        if ((rc = launch_run(env, kModePolicyStep, nsteps, nullptr, nullptr, nullptr, env->d_out))) return rc;
+        HIP_TRY(env, hipMemcpyAsync(out, env->d_out, n * sizeof(ongym_step_rec), hipMemcpyDeviceToHost, env->stream));
+        HIP_TRY(env, hipStreamSynchronize(env->stream));
+        return ONGYM_OK;
+    }
+    return launch_run(env, kModePolicyStep, nsteps, nullptr, nullptr, nullptr, out);
+}
+
+int ongym_step_actions(ongym_env *env, const int32_t *actions, ongym_step_rec *out) {
+    if (!env || !actions) return env ? fail_arg(env, "null actions") : ONGYM_E_ARG;
+    if (!env->has_source) { env->err = "no request source: call ongym_seed or ongym_set_requests first"; return ONGYM_E_STATE; }
+    HIP_TRY(env, hipSetDevice(env->cfg.device));
+    int rc;
+    if (env->cfg.io_device) return launch_run(env, kModeActionStep, 1, actions, nullptr, nullptr, out);
+    HIP_TRY(env, hipMemcpyAsync(env->d_actions, actions, (size_t)env->P.batch * 4, hipMemcpyHostToDevice, env->stream));
+    if (out) {
+        if ((rc = ensure_out(env, (size_t)env->P.batch))) return rc;
+        if ((rc = launch_run(env, kModeActionStep, 1, env->d_actions, nullptr, nullptr, env->d_out))) return rc;
+        HIP_TRY(env, hipMemcpyAsync(out, env->d_out, (size_t)env->P.batch * sizeof(ongym_step_rec), hipMemcpyDeviceToHost, env->stream));
+    } else if ((rc = launch_run(env, kModeActionStep, 1, env->d_actions, nullptr, nullptr, nullptr))) return rc;
+    HIP_TRY(env, hipStreamSynchronize(env->stream));
+    return ONGYM_OK;
+}
+
+int ongym_policy_actions(ongym_env *env, int32_t policy, int32_t *actions, uint8_t *flags) {
+    if (!env || !actions) return env ? fail_arg(env, "null actions") : ONGYM_E_ARG;
+    if (policy != ONGYM_POLICY_FIRST_FIT) return fail_arg(env, "unknown policy id");
+    HIP_TRY(env, hipSetDevice(env->cfg.device));
+    int rc;
+    if (env->cfg.io_device) return launch_run(env, kModePolicyOnly, 1, nullptr, actions, flags, nullptr);
+    if ((rc = launch_run(env, kModePolicyOnly, 1, nullptr, env->d_act_out, env->d_flag_out, nullptr))) return rc;
+    HIP_TRY(env, hipMemcpyAsync(actions, env->d_act_out, (size_t)env->P.batch * 4, hipMemcpyDeviceToHost, env->stream));
+    if (flags) HIP_TRY(env, hipMemcpyAsync(flags, env->d_flag_out, (size_t)env->P.batch, hipMemcpyDeviceToHost, env->stream));
+    HIP_TRY(env, hipStreamSynchronize(env->stream));
+    return ONGYM_OK;
+}
+
+static int query(ongym_env *env, int what, int replica, int path, int slot, int n) {
+    if (replica < 0 || replica >= env->P.batch) return fail_arg(env, "replica out of range");
+    if ((what == kQAvailable || what == kQGsnr) && (path < 0 || path >= env->P.n_paths)) return fail_arg(env, "path id out of range");
+    if (what == kQGsnr && (slot < 0 || n <= 0 || slot + n > env->P.n_slots)) return fail_arg(env, "slot range out of the grid");
+    HIP_TRY(env, hipSetDevice(env->cfg.device));
+    if (env->P.uniform_alpha)
+        hipLaunchKernelGGL(k_query<true>, dim3(1), dim3(64), env->lds, env->stream, env->P, what, replica, path, slot, n, env->d_scratch_i, env->d_scratch_d);
+    else
+        hipLaunchKernelGGL(k_query<false>, dim3(1), dim3(64), env->lds, env->stream, env->P, what, replica, path, slot, n, env->d_scratch_i, env->d_scratch_d);
+    HIP_TRY(env, hipGetLastError());
+    return 0;
+}
+
+int ongym_query_available(ongym_env *env, int32_t replica, int32_t path_id, int32_t *out) {
+    if (!env || !out) return ONGYM_E_ARG;
+    int rc = query(env, kQAvailable, replica, path_id, 0, 0);
+    if (rc) return rc;
+    HIP_TRY(env, hipMemcpyAsync(out, env->d_scratch_i, (size_t)env->P.n_slots * 4, hipMemcpyDeviceToHost, env->stream));
+    HIP_TRY(env, hipStreamSynchronize(env->stream));
+    return ONGYM_OK;
+}
+
+int ongym_query_gsnr(ongym_env *env, int32_t replica, int32_t path_id, int32_t slot, int32_t nslots, double out[3]) {
+    if (!env || !out) return ONGYM_E_ARG;
+    int rc = query(env, kQGsnr, replica, path_id, slot, nslots);
+    if (rc) return rc;
+    HIP_TRY(env, hipMemcpyAsync(out, env->d_scratch_d, 3 * sizeof(double), hipMemcpyDeviceToHost, env->stream));
+    HIP_TRY(env, hipStreamSynchronize(env->stream));
+    return ONGYM_OK;
+}
+
+int ongym_query_grid(ongym_env *env, int32_t replica, int32_t *out) {
+    if (!env || !out) return ONGYM_E_ARG;
+    int rc = query(env, kQGrid, replica, 0, 0, 0);
+    if (rc) return rc;
+    HIP_TRY(env, hipMemcpyAsync(out, env->d_scratch_i, (size_t)env->P.n_links * env->P.n_slots * 4, hipMemcpyDeviceToHost, env->stream));
+    HIP_TRY(env, hipStreamSynchronize(env->stream));
+    return ONGYM_OK;
+}
+
+int ongym_query_services(ongym_env *env, int32_t replica, ongym_service *out, int32_t *n) {
+    if (!env || !out || !n) return ONGYM_E_ARG;
+    int rc = query(env, kQServices, replica, 0, 0, 0);
+    if (rc) return rc;
+    int32_t head[2];
+    HIP_TRY(env, hipMemcpyAsync(head, env->d_scratch_i, 8, hipMemcpyDeviceToHost, env->stream));
+    HIP_TRY(env, hipStreamSynchronize(env->stream));
+    *n = head[0];
+    if (head[0] > 0) HIP_TRY(env, hipMemcpy(out, env->d_scratch_i + 2, (size_t)head[0] * sizeof(ongym_service), hipMemcpyDeviceToHost));
+    return ONGYM_OK;
+}
+
+int ongym_query_request(ongym_env *env, int32_t replica, ongym_request *out) {
+    if (!env || !out) return ONGYM_E_ARG;
+    int rc = query(env, kQRequest, replica, 0, 0, 0);
+    if (rc) return rc;
+    HIP_TRY(env, hipMemcpyAsync(out, env->d_scratch_i, sizeof(ongym_request), hipMemcpyDeviceToHost, env->stream));
+    HIP_TRY(env, hipStreamSynchronize(env->stream));
+    return ONGYM_OK;
+}
+
+int ongym_stats_get(ongym_env *env, ongym_stats *out) {
+    if (!env || !out) return ONGYM_E_ARG;
+    HIP_TRY(env, hipSetDevice(env->cfg.device));
+    HIP_TRY(env, hipStreamSynchronize(env->stream));
+    std::vector<DevEnv> host((size_t)env->P.batch);
+    HIP_TRY(env, hipMemcpy(host.data(), env->P.env, host.size() * sizeof(DevEnv), hipMemcpyDeviceToHost));
+    int flags = 0;
+    for (size_t r = 0; r < host.size(); r++) { out[r] = host[r].st; flags |= host[r].st.flags; }
+    if (flags & ONGYM_F_OVERFLOW) { env->err = "a replica overflowed its service table (raise capacity)"; return ONGYM_E_CAPACITY; }
+    return ONGYM_OK;
+}
+
+}  // extern "C"

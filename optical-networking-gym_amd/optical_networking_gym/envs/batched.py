@@ -1,0 +1,164 @@
+"""Batched QRMSA environment: B independent replicas stepped by the HIP kernels behind include/ongym.h.
+
+This is the host-side mirror of the reference's `QRMSAEnv` (envs/qrmsa.pyx:118-1644) for the hot path only:
+constructor kwargs keep the reference's names (qrmsa.pyx:206-237) plus `batch_size`, `capacity`, `auto_reset`,
+`device`; `reset()/step()` keep their meaning per replica; the first-fit heuristic
+(heuristics/heuristics.py:923-966) is fused on device (`step_policy`).
+
+The class is a thin ctypes shim: no arithmetic of the hot path happens in Python, and there is no CPU fallback —
+constructing it without a built libongym_hip.so or without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from .. import _native as nat
+from .._tables import StaticTables
+
+
+class OngymError(RuntimeError):
+    pass
+
+
+class BatchedQRMSAEnv:
+    def __init__(self, topology=None, *, tables: Optional[StaticTables] = None, batch_size: int = 1,
+                 modulations: Optional[Sequence] = None, capacity: int = 1024, auto_reset: bool = True,
+                 device: int = 0, io_device: bool = False, **kwargs):
+        if tables is None:
+            if topology is None:
+                raise ValueError("need a topology graph (from get_topology) or StaticTables")
+            tables = StaticTables.from_topology(topology)
+        if modulations is None:
+            modulations = topology.graph.get("modulations") if topology is not None else None
+        if not modulations:
+            raise ValueError("no modulations: pass `modulations=` or build the topology with them")
+        mtc = kwargs.pop("modulations_to_consider", 6)
+        modulations = list(modulations)[:min(mtc, len(modulations))] if mtc < len(modulations) else list(modulations)
+        for dead in ("seed", "allow_rejection", "reset", "file_name", "blocks_to_consider", "gen_observation",
+                     "measure_disruptions", "defragmentation", "n_defrag_services", "bands", "bandwidth", "k_paths"):
+            kwargs.pop(dead, None)
+        self.holder = nat.ConfigHolder(tables, modulations=modulations, batch=batch_size, capacity=capacity,
+                                       auto_reset=auto_reset, device=device, io_device=io_device, **kwargs)
+        self.tables = tables
+        self.modulations = modulations
+        self.batch_size = int(batch_size)
+        self.lib = nat.load_library()
+        h = C.c_void_p()
+        rc = self.lib.ongym_create(C.byref(self.holder.struct), C.byref(h))
+        if rc != 0:
+            raise OngymError(f"ongym_create failed ({rc}): {self.lib.ongym_last_error(None).decode()}")
+        self._h = h
+        self._trace = None
+
+    # ------------------------------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.ongym_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise OngymError(f"{what} failed ({rc}): {self.lib.ongym_last_error(self._h).decode()}")
+
+    @property
+    def reject_action(self) -> int:
+        return self.holder.reject_action
+
+    @property
+    def num_actions(self) -> int:
+        return self.holder.reject_action + 1
+
+    # ---- request sources -----------------------------------------------------------------------------------------
+    def seed(self, seed: int):
+        """Device traffic generator; replica r uses stream (seed, r) of include/ongym_traffic.h."""
+        self._check(self.lib.ongym_seed(self._h, C.c_uint64(seed)), "ongym_seed")
+
+    def set_requests(self, requests: np.ndarray):
+        """Trace replay: `requests` is a REQUEST_DTYPE array [batch, n] (or [n] for batch 1)."""
+        req = np.ascontiguousarray(requests, nat.REQUEST_DTYPE)
+        if req.ndim == 1:
+            req = req[None, :]
+        if req.shape[0] != self.batch_size:
+            raise ValueError("requests must have one row per replica")
+        self._trace = req
+        self._check(self.lib.ongym_set_requests(self._h, req.ctypes.data, req.shape[1]), "ongym_set_requests")
+
+    # ---- reset / step -----------------------------------------------------------------------------------------------
+    def reset(self, mask: Optional[np.ndarray] = None):
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, np.uint8)
+            if mask.shape != (self.batch_size,):
+                raise ValueError("mask must have one entry per replica")
+        self._check(self.lib.ongym_reset(self._h, mask.ctypes.data if mask is not None else None), "ongym_reset")
+
+    def step_policy(self, nsteps: int = 1, record: bool = True, policy: int = nat.POLICY_FIRST_FIT):
+        """`nsteps` x {first-fit heuristic; step}. Returns STEP_DTYPE [nsteps, batch] when `record`, else None."""
+        out = np.zeros((nsteps, self.batch_size), nat.STEP_DTYPE) if record else None
+        self._check(self.lib.ongym_step_policy(self._h, policy, nsteps, out.ctypes.data if record else None),
+                    "ongym_step_policy")
+        return out
+
+    def step(self, actions: np.ndarray) -> np.ndarray:
+        actions = np.ascontiguousarray(actions, np.int32)
+        if actions.shape != (self.batch_size,):
+            raise ValueError("actions must have one entry per replica")
+        out = np.zeros(self.batch_size, nat.STEP_DTYPE)
+        self._check(self.lib.ongym_step_actions(self._h, actions.ctypes.data, out.ctypes.data), "ongym_step_actions")
+        return out
+
+    def policy_actions(self, policy: int = nat.POLICY_FIRST_FIT):
+        actions = np.zeros(self.batch_size, np.int32)
+        flags = np.zeros(self.batch_size, np.uint8)
+        self._check(self.lib.ongym_policy_actions(self._h, policy, actions.ctypes.data, flags.ctypes.data),
+                    "ongym_policy_actions")
+        return actions, flags
+
+    # ---- queries (plugin API) ----------------------------------------------------------------------------------------
+    def available_slots(self, replica: int, path_id: int) -> np.ndarray:
+        out = np.zeros(self.holder.struct.n_slots, np.int32)
+        self._check(self.lib.ongym_query_available(self._h, replica, path_id, out.ctypes.data), "ongym_query_available")
+        return out
+
+    def gsnr(self, replica: int, path_id: int, slot: int, nslots: int) -> np.ndarray:
+        out = np.zeros(3, np.float64)
+        self._check(self.lib.ongym_query_gsnr(self._h, replica, path_id, slot, nslots, out.ctypes.data),
+                    "ongym_query_gsnr")
+        return out
+
+    def grid(self, replica: int) -> np.ndarray:
+        c = self.holder.struct
+        out = np.zeros((c.n_links, c.n_slots), np.int32)
+        self._check(self.lib.ongym_query_grid(self._h, replica, out.ctypes.data), "ongym_query_grid")
+        return out
+
+    def services(self, replica: int) -> np.ndarray:
+        out = np.zeros(self.holder.struct.capacity, nat.SERVICE_DTYPE)
+        n = C.c_int32(0)
+        self._check(self.lib.ongym_query_services(self._h, replica, out.ctypes.data, C.byref(n)),
+                    "ongym_query_services")
+        return out[:n.value]
+
+    def request(self, replica: int):
+        out = np.zeros(1, nat.REQUEST_DTYPE)
+        self._check(self.lib.ongym_query_request(self._h, replica, out.ctypes.data), "ongym_query_request")
+        return out[0]
+
+    def stats(self) -> np.ndarray:
+        out = np.zeros(self.batch_size, nat.STATS_DTYPE)
+        self._check(self.lib.ongym_stats_get(self._h, out.ctypes.data), "ongym_stats_get")
+        return out
+
+    def sync(self):
+        self._check(self.lib.ongym_sync(self._h), "ongym_sync")
+
+    def last_kernel_ms(self) -> float:
+        return float(self.lib.ongym_last_kernel_ms(self._h))

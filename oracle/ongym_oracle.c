@@ -297,7 +297,7 @@ static void gn_core(const orc_env *e, int path_id, double fc, double bw, double 
                               - asinh(pi * pi * fabs(beta_2) * l_eff_a * r->bw * (r->fc - fc - (r->bw / 2.0))))
                              - (PHI_MOD[r->se - 1] * (r->bw / fabs(r->fc - fc)) * (5.0 / 3.0) * (l_eff / (L * 1e3)));
                 sum_phi += phi;
-                if (terms) (*terms)++;
+                if (terms && sp == 0) (*terms)++;   /* interferer x link terms (the span loop repeats them) */
             }
             double ratio = P / bw;
             double power_nli_span = (ratio * ratio * ratio) * (8.0 / (27.0 * pi * fabs(beta_2))) * (gamma * gamma)
@@ -318,8 +318,8 @@ static double center_freq(const orc_env *e, int slot, int n) {
     return e->cfg.frequency_start + (e->cfg.slot_bandwidth * slot) + (e->cfg.slot_bandwidth * (n / 2.0));
 }
 
-/* GN of a candidate against the CURRENT state */
-void orc_gn(orc_env *e, int path_id, int slot, int n, double out[3]) {
+/* GN of a candidate against the CURRENT state; `count` = add to the evaluation / term statistics */
+static void gn_state(orc_env *e, int path_id, int slot, int n, double out[3], int count) {
     int H = e->cfg.max_hops, hops = e->path_hops[path_id];
     const orc_intf *lists[ORC_MAX_HOPS]; int counts[ORC_MAX_HOPS];
     orc_intf *buf = (orc_intf *)malloc(sizeof(orc_intf) * (size_t)(e->n_running + 1) * hops);
@@ -333,11 +333,12 @@ void orc_gn(orc_env *e, int path_id, int slot, int n, double out[3]) {
             buf[off].id = s->id; off++;
         }
     }
-    e->total_gn++;
+    if (count) e->total_gn++;
     gn_core(e, path_id, center_freq(e, slot, n), e->cfg.slot_bandwidth * n, e->launch_power, -1, lists, counts, out,
-            &e->total_terms);
+            count ? &e->total_terms : 0);
     free(buf);
 }
+void orc_gn(orc_env *e, int path_id, int slot, int n, double out[3]) { gn_state(e, path_id, slot, n, out, 0); }
 
 /* GN with explicit per-link interferer lists (for the captured known-answer tests):
  * intf = flat (slot, n, se) triples, link h owns counts[h] consecutive triples. */
@@ -393,7 +394,8 @@ int orc_policy_first_fit(orc_env *e, int *blocked_resources, int *blocked_osnr) 
             int cnt = orc_candidates(avail, S, req, &first, 1);
             if (cnt == 0) { bres = 1; continue; }
             double o[3];
-            orc_gn(e, p, first, req, o);
+            gn_state(e, p, first, req, o, 1);   /* statistics count the policy's evaluations only: the fused device
+                                                   path does not repeat step()'s identical re-evaluation (:909) */
             double threshold = e->mod_thr[m] + e->margin;
             if (o[0] >= threshold) {
                 action = orc_encode_action(e, k, m, first);

@@ -1,0 +1,279 @@
+"""Parity of the HIP path (through the C ABI) against (a) the golden vectors captured from the reference and
+(b) the CPU oracle on seeded random traffic.  Bar: bit-exact for actions / slots / blocking decisions / counters,
+GSNR within GSNR_RTOL (the north star allows 1e-5 relative; the fp64 span-hoisted device sum is held to 1e-9)."""
+import numpy as np
+import pytest
+
+from common import ALL_TRAJ, golden_tables, holder_for, jocn_modulations, load_traj, traj_requests
+from optical_networking_gym import _native as nat
+from optical_networking_gym.envs.batched import BatchedQRMSAEnv, OngymError
+from oracle_lib import OracleEnv
+
+pytestmark = pytest.mark.gpu
+
+GSNR_RTOL = 1e-9
+EXACT = ("action", "route", "modulation", "slot", "nslots", "accepted", "terminated", "retry", "flags", "active",
+         "reward")
+
+
+def make_env(meta, batch=1, **over):
+    kw = dict(tables=golden_tables(meta["topology"]), modulations=jocn_modulations(), batch_size=batch,
+              num_spectrum_resources=meta["S"], episode_length=meta["episode_length"], load=meta["load"],
+              mean_service_holding_time=meta["mean_holding"], bit_rate_selection=meta["bit_rate_selection"],
+              bit_rates=tuple(meta["bit_rates"]), bit_rate_lower_bound=25, bit_rate_higher_bound=100,
+              launch_power_dbm=meta["launch_power_dbm"], frequency_start=meta["frequency_start"],
+              frequency_slot_bandwidth=meta["slot_bw"], margin=meta["margin"], capacity=1024)
+    kw.update(over)
+    return BatchedQRMSAEnv(**kw)
+
+
+def assert_records_equal(got, want, ctx=""):
+    for f in EXACT:
+        if not np.array_equal(got[f], want[f]):
+            bad = np.argwhere(got[f] != want[f])[0]
+            raise AssertionError(f"{ctx}: field {f} differs first at {tuple(bad)}: {got[f][tuple(bad)]} != {want[f][tuple(bad)]}")
+    for f in ("osnr", "ase", "nli"):
+        np.testing.assert_allclose(got[f], want[f], rtol=GSNR_RTOL, err_msg=f"{ctx}: {f}")
+
+
+@pytest.mark.parametrize("tag", ALL_TRAJ)
+def test_first_fit_trajectory_vs_reference(tag):
+    """Replays the reference's captured request trace; every step of the fused policy+step kernel must reproduce the
+    reference's action, slot, modulation, accept decision, reward, termination and GSNR."""
+    meta, d = load_traj(tag)
+    env = make_env(meta, auto_reset=True)
+    env.set_requests(traj_requests(d))
+    for _ in range(meta["initial_resets"]):
+        env.reset()
+    n = meta["n_steps"]
+    rec = env.step_policy(n)[:, 0]
+    assert np.array_equal(rec["action"], d["st_action"])
+    assert np.array_equal(rec["accepted"], d["st_accepted"])
+    assert np.array_equal(rec["terminated"], d["st_term"])
+    assert np.array_equal(rec["reward"], d["st_reward"])
+    assert np.array_equal(rec["active"], d["st_active"])
+    assert np.array_equal(rec["route"], d["st_route"])
+    assert np.array_equal(rec["slot"], d["st_slot"])
+    acc = d["st_accepted"] == 1
+    assert np.array_equal(rec["modulation"][acc], d["st_mod"][acc])
+    assert np.array_equal(rec["nslots"][acc], d["st_n"][acc])
+    assert np.array_equal((rec["flags"] & nat.F_BLOCKED_RESOURCES) != 0, d["st_bres"] == 1)
+    assert np.array_equal((rec["flags"] & nat.F_BLOCKED_OSNR) != 0, d["st_bosnr"] == 1)
+    for f, g in (("osnr", "st_osnr"), ("ase", "st_ase"), ("nli", "st_nli")):
+        np.testing.assert_allclose(rec[f], d[g], rtol=GSNR_RTOL)
+    st = env.stats()[0]
+    ti = meta["terminal_infos"][-1]
+    assert st["episodes_completed"] == meta["episodes"]
+    assert st["last_episode_accepted"] == ti["episode_services_accepted"]
+    assert st["last_rejected"] == ti["rejected"]
+    assert st["last_service_blocking_rate"] == pytest.approx(ti["service_blocking_rate"], rel=1e-12, abs=1e-15)
+    assert st["last_episode_bit_rate_blocking_rate"] == pytest.approx(ti["episode_bit_rate_blocking_rate"], rel=1e-12, abs=1e-15)
+    assert st["last_mean_gsnr"] == pytest.approx(ti["mean_gsnr"], rel=1e-9)
+    for m, mod in enumerate(jocn_modulations()):
+        assert st["last_modulation_hist"][m] == ti[f"modulation_{float(mod.spectral_efficiency)}"]
+
+
+def test_grid_snapshots_vs_reference():
+    meta, d = load_traj("traj_nsfnet320")
+    env = make_env(meta, auto_reset=False)
+    env.set_requests(traj_requests(d))
+    for _ in range(meta["initial_resets"]):
+        env.reset()
+    done = 0
+    for k, s in enumerate(d["snap_step"]):
+        env.step_policy(int(s) + 1 - done, record=False)
+        done = int(s) + 1
+        want = np.unpackbits(d["snap_grid"][k], axis=1, bitorder="little")[:, :meta["S"]].astype(np.int32)
+        np.testing.assert_array_equal(env.grid(0), want)
+
+
+def test_scripted_actions_vs_reference():
+    """step(action) with reject actions and occupied-slot actions (quirk Q5), one launch per step."""
+    meta, d = load_traj("traj_nsfnet320_scripted")
+    env = make_env(meta, auto_reset=False)
+    env.set_requests(traj_requests(d))
+    for _ in range(meta["initial_resets"]):
+        env.reset()
+    for i in range(meta["n_steps"]):
+        r = env.step(np.array([d["st_action"][i]], np.int32))[0]
+        assert r["retry"] == d["st_retry"][i], i
+        assert r["accepted"] == d["st_accepted"][i], i
+        assert r["reward"] == d["st_reward"][i], i
+        assert r["active"] == d["st_active"][i], i
+        if not r["retry"]:
+            assert r["terminated"] == d["st_term"][i]
+            assert r["route"] == d["st_route"][i] and r["slot"] == d["st_slot"][i]
+            if r["accepted"]:
+                assert r["modulation"] == d["st_mod"][i] and r["nslots"] == d["st_n"][i]
+                np.testing.assert_allclose(r["osnr"], d["st_osnr"][i], rtol=GSNR_RTOL)
+
+
+def test_gn_known_answers_vs_reference():
+    """calculate_osnr on the empty network: every modulation / several paths and slots (core/osnr.pyx:21-142)."""
+    import json, os
+    from common import GOLDEN
+    kats = json.load(open(os.path.join(GOLDEN, "kats_nsfnet320.json")))
+    meta, d = load_traj("traj_nsfnet320")
+    env = make_env(meta)
+    env.set_requests(traj_requests(d)[:2])
+    env.reset()
+    for case in kats["gn_empty"][::7]:
+        out = env.gsnr(0, case["path_id"], case["slot"], case["n"])
+        np.testing.assert_allclose(out, case["out"], rtol=GSNR_RTOL)
+
+
+def run_oracle_batch(holder, seed, nsteps, batch):
+    recs = np.zeros((nsteps, batch), nat.STEP_DTYPE)
+    envs = []
+    for r in range(batch):
+        o = OracleEnv(holder, replica=r)
+        o.seed(seed)
+        o.reset()
+        recs[:, r] = o.run_first_fit(nsteps)
+        envs.append(o)
+    return recs, envs
+
+
+@pytest.mark.parametrize("topo,S,load,steps", [("nsfnet", 320, 300, 1300), ("cost239", 320, 400, 700),
+                                                ("nobel-eu", 768, 600, 700), ("germany50", 320, 500, 400)])
+def test_random_traffic_vs_oracle(topo, S, load, steps):
+    """Device request generator + fused step vs the CPU oracle on the same (seed, replica) streams, B=48 replicas with
+    per-replica load / launch power / margin overrides; crosses an episode boundary (auto-reset)."""
+    B = 48
+    rng = np.random.default_rng(1)
+    loads = load * rng.uniform(0.5, 1.6, B)
+    lps = rng.uniform(-4.0, 3.0, B)
+    margins = rng.choice([0.0, 0.5, 1.0], B)
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=S, batch=B, capacity=1024, episode_length=1000,
+              auto_reset=True, load=load, bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400),
+              replica_load=loads, replica_launch_power_dbm=lps, replica_margin=margins)
+    holder = nat.ConfigHolder(golden_tables(topo), **kw)
+    want, oracles = run_oracle_batch(holder, 2024, steps, B)
+    env = BatchedQRMSAEnv(tables=golden_tables(topo), modulations=jocn_modulations(), batch_size=B,
+                          num_spectrum_resources=S, capacity=1024, episode_length=1000, auto_reset=True, load=load,
+                          bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), replica_load=loads,
+                          replica_launch_power_dbm=lps, replica_margin=margins)
+    env.seed(2024)
+    env.reset()
+    got = env.step_policy(steps)
+    assert_records_equal(got, want, f"{topo}")
+    st = env.stats()
+    for r in (0, 7, B - 1):
+        o = oracles[r].stats()
+        for f in ("services_processed", "services_accepted", "episode_services_processed", "episode_services_accepted",
+                  "bit_rate_requested", "bit_rate_provisioned", "episode_bit_rate_provisioned", "rejected",
+                  "episodes_completed", "total_steps", "total_accepted", "total_gn_evals", "total_interferer_terms",
+                  "current_time", "active", "last_episode_accepted", "last_service_blocking_rate"):
+            assert st[r][f] == o[f], (r, f, st[r][f], o[f])
+        np.testing.assert_array_equal(st[r]["episode_modulation_hist"], o["episode_modulation_hist"])
+        np.testing.assert_array_equal(env.grid(r), oracles[r].grid())
+        # plugin-API queries on a loaded network
+        q = env.request(r)
+        assert q.tobytes() == oracles[r].request().tobytes()
+        tb = golden_tables(topo)
+        p = int(tb.pair_paths[q["source"], q["destination"], 0])
+        np.testing.assert_array_equal(env.available_slots(r, p), oracles[r].available(p))
+        starts = oracles[r].candidates(oracles[r].available(p), 4)
+        for s0 in starts[:1] + starts[-1:]:
+            np.testing.assert_allclose(env.gsnr(r, p, s0, 4), oracles[r].gn(p, s0, 4), rtol=GSNR_RTOL)
+        a = np.sort(env.services(r), order=["release_time", "path_id", "slot"])
+        b = np.sort(oracles[r].services(), order=["release_time", "path_id", "slot"])
+        assert a.tobytes() == b.tobytes()
+
+
+def test_nonuniform_attenuation_vs_oracle():
+    """per-link alpha (template path UNIFORM_ALPHA=false)."""
+    import copy
+    tb = copy.deepcopy(golden_tables("nsfnet"))
+    tb.link_alpha = tb.link_alpha * np.linspace(0.9, 1.2, tb.n_links)
+    B, steps = 8, 600
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=320, batch=B, capacity=1024, load=300,
+              bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), auto_reset=True)
+    holder = nat.ConfigHolder(tb, **kw)
+    want, _ = run_oracle_batch(holder, 5, steps, B)
+    env = BatchedQRMSAEnv(tables=tb, modulations=jocn_modulations(), batch_size=B, num_spectrum_resources=320,
+                          capacity=1024, load=300, bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400))
+    env.seed(5); env.reset()
+    assert_records_equal(env.step_policy(steps), want, "nonuniform")
+
+
+def test_policy_actions_matches_step_and_is_pure():
+    meta, d = load_traj("traj_nsfnet320")
+    env = make_env(meta, batch=16, load=450)
+    env.seed(3); env.reset()
+    env.step_policy(300, record=False)
+    before = env.grid(5).copy()
+    acts, flags = env.policy_actions()
+    np.testing.assert_array_equal(env.grid(5), before)
+    rec = env.step(acts)
+    assert np.array_equal(rec["action"], acts)
+    assert not rec["retry"].any() and not (rec["flags"] & nat.F_QOT_ERROR).any()
+    assert np.array_equal(rec["accepted"] == 0, acts == env.reject_action)
+
+
+def test_qot_infeasible_action_is_flagged_not_applied():
+    """The reference raises ValueError (qrmsa.pyx:925-929): 64QAM over a 3450 km path fails QoT on an empty network."""
+    meta, d = load_traj("traj_nsfnet320")
+    env = make_env(meta)
+    reqs = traj_requests(d)[:4].copy()
+    reqs["source"], reqs["destination"], reqs["bit_rate"] = 0, 12, 400.0
+    env.set_requests(reqs)
+    env.reset()
+    rec = env.step(np.array([0], np.int32))[0]     # path 0, relative modulation 0 = 64QAM, slot 0
+    assert rec["flags"] & nat.F_QOT_ERROR and not rec["accepted"]
+    assert env.services(0).size == 0 and env.grid(0).all()
+    assert env.request(0)["bit_rate"] == 400.0 and env.stats()[0]["total_steps"] == 0
+
+
+def test_masked_reset_and_capacity_overflow():
+    meta, d = load_traj("traj_nsfnet320")
+    env = make_env(meta, batch=4, capacity=64, load=600)
+    env.seed(9); env.reset()
+    env.step_policy(400, record=False)
+    with pytest.raises(OngymError):
+        env.stats()                                   # 64 concurrent services cannot hold load 600
+    env = make_env(meta, batch=4, load=300)
+    env.seed(9); env.reset()
+    env.step_policy(200, record=False)
+    g1 = env.grid(1).copy()
+    env.reset(np.array([1, 0, 1, 0], np.uint8))
+    assert env.grid(0).all() and env.grid(2).all()
+    np.testing.assert_array_equal(env.grid(1), g1)
+    st = env.stats()
+    assert st[0]["episode_services_processed"] == 1 and st[1]["episode_services_processed"] == 201
+
+
+def check_state_invariants(env, tables, replica, S):
+    """grid == complement of the union of the running services' [slot, slot+n(+1 guard)) on their links."""
+    svc = env.services(replica)
+    grid = np.ones((tables.n_links, S), np.int32)
+    for s in svc:
+        end = s["slot"] + s["nslots"]
+        end = end + 1 if end < S else end
+        for l in tables.path_links[s["path_id"]][:tables.path_hops[s["path_id"]]]:
+            assert grid[l, s["slot"]:end].all(), "overlapping allocations"
+            grid[l, s["slot"]:end] = 0
+    np.testing.assert_array_equal(env.grid(replica), grid)
+
+
+def test_full_batch_invariants_nsfnet_4096():
+    """BASELINE config 2 size (B=4096): size-independent properties — determinism, state consistency, conservation."""
+    tb = golden_tables("nsfnet")
+    kw = dict(tables=tb, modulations=jocn_modulations(), batch_size=4096, num_spectrum_resources=320, capacity=512,
+              load=300, bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), episode_length=1000)
+    a = BatchedQRMSAEnv(**kw); a.seed(11); a.reset(); a.step_policy(1500, record=False)
+    b = BatchedQRMSAEnv(**kw); b.seed(11); b.reset()
+    for _ in range(3):
+        b.step_policy(500, record=False)             # launch partition must not matter
+    sa, sb = a.stats(), b.stats()
+    assert sa.tobytes() == sb.tobytes()
+    assert (sa["total_steps"] == 1500).all() and (sa["episodes_completed"] == 1).all()
+    assert (sa["services_processed"] == 1502).all()  # 1500 steps + initial request + the one dropped at the boundary
+    assert (sa["episode_services_accepted"] + sa["rejected"] == sa["episode_services_processed"] - 1).all()
+    blocking = 1 - sa["total_accepted"].sum() / sa["total_steps"].sum()
+    assert 0.0 <= blocking < 0.05                     # reference: 0.0187 at load 300 in steady state
+    for r in (0, 1234, 4095):
+        check_state_invariants(a, tb, r, 320)
+        assert len(a.services(r)) == sa[r]["active"]
+    c = BatchedQRMSAEnv(**kw); c.seed(12); c.reset(); c.step_policy(200, record=False)
+    assert c.stats()["services_accepted"].tobytes() != sa["services_accepted"].tobytes()
