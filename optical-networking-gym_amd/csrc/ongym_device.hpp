@@ -105,6 +105,8 @@ struct Ctx {
     float min_rel;     // wave-uniform
     int lane_terms;    // per-lane interferer-link term counter (reduced once per launch)
     int gn_evals;      // wave-uniform
+    int paths_tried, path_hops;   // wave-uniform statistics
+    long long active_sum;
     __device__ Ctx(const Params &p) : P(p) {}
 };
 
@@ -331,6 +333,7 @@ __device__ __forceinline__ void policy_first_fit(Ctx &c, int src, int dst, doubl
         int path = P.pair_paths[(src * P.n_nodes + dst) * P.k_paths + k];
         if (path < 0) break;
         PathRef p = load_path(c, path);
+        c.paths_tried++; c.path_hops += p.hops;
         uint64_t free_ext = path_free_ext(c, p);
         int L = -1;
         for (int m = max_mod; m >= 0; m--) {
@@ -568,6 +571,7 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
     __syncthreads();
     release_due(c, e->cur_at);                    // second half of _next_service (:1113-1122)
     if (rec && c.lane == 0) rec->active = c.active;
+    c.active_sum += c.active;
     int terminated = e->st.episode_services_processed == P.episode_length;
     if (terminated && P.auto_reset) reset_env(c);
 }
@@ -602,6 +606,9 @@ __device__ __forceinline__ void store_state(Ctx &c) {
         c.e->min_rel = c.min_rel;
         c.e->st.total_gn_evals += c.gn_evals;
         c.e->st.total_interferer_terms += terms;
+        c.e->st.total_paths_tried += c.paths_tried;
+        c.e->st.total_path_hops += c.path_hops;
+        c.e->st.total_active_sum += c.active_sum;
     }
     __syncthreads();
     uint64_t *ge = reinterpret_cast<uint64_t *>(P.env + c.replica);

@@ -25,6 +25,7 @@ __global__ __launch_bounds__(64) void k_run(Params P, int mode, int nsteps, cons
     c.replica = blockIdx.x;
     c.lane_terms = 0;
     c.gn_evals = 0;
+    c.paths_tried = 0; c.path_hops = 0; c.active_sum = 0;
     ctx_bind(c, smem);
     load_state(c);
     for (int it = 0; it < nsteps; ++it) {
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(64) void k_reset(Params P, const uint8_t *mask) {
     c.replica = blockIdx.x;
     c.lane_terms = 0;
     c.gn_evals = 0;
+    c.paths_tried = 0; c.path_hops = 0; c.active_sum = 0;
     ctx_bind(c, smem);
     load_state(c);
     reset_env(c);
@@ -99,6 +101,7 @@ __global__ __launch_bounds__(64) void k_query(Params P, int what, int replica, i
     c.replica = replica;
     c.lane_terms = 0;
     c.gn_evals = 0;
+    c.paths_tried = 0; c.path_hops = 0; c.active_sum = 0;
     ctx_bind(c, smem);
     load_state(c);
     if (what == kQAvailable) {          // get_available_slots(path), envs/qrmsa.pyx:1482-1512
@@ -384,14 +387,14 @@ int ongym_create(const ongym_config *cfg, ongym_env **out) {
 
 void ongym_destroy(ongym_env *env) {
     if (!env) return;
-    hipSetDevice(env->cfg.device);
-    if (env->stream) hipStreamSynchronize(env->stream);
-    for (void *p : env->allocs) hipFree(p);
-    if (env->d_trace) hipFree(env->d_trace);
-    if (env->d_out) hipFree(env->d_out);
-    if (env->ev0) hipEventDestroy(env->ev0);
-    if (env->ev1) hipEventDestroy(env->ev1);
-    if (env->stream) hipStreamDestroy(env->stream);
+    (void)hipSetDevice(env->cfg.device);
+    if (env->stream) (void)hipStreamSynchronize(env->stream);
+    for (void *p : env->allocs) (void)hipFree(p);
+    if (env->d_trace) (void)hipFree(env->d_trace);
+    if (env->d_out) (void)hipFree(env->d_out);
+    if (env->ev0) (void)hipEventDestroy(env->ev0);
+    if (env->ev1) (void)hipEventDestroy(env->ev1);
+    if (env->stream) (void)hipStreamDestroy(env->stream);
     delete env;
 }
 
@@ -434,7 +437,7 @@ int ongym_set_requests(ongym_env *env, const ongym_request *reqs, int64_t n_per_
                 q.source == q.destination || !(q.bit_rate > 0))
                 return fail_arg(env, "trace entry with invalid node pair / bit rate");
         }
-        if (env->d_trace) { hipFree(env->d_trace); env->d_trace = nullptr; }
+        if (env->d_trace) { (void)hipFree(env->d_trace); env->d_trace = nullptr; }
         HIP_TRY(env, hipMalloc(&env->d_trace, n * sizeof(ongym_request)));
         HIP_TRY(env, hipMemcpy(env->d_trace, reqs, n * sizeof(ongym_request), hipMemcpyHostToDevice));
         env->P.trace = static_cast<const ongym_request *>(env->d_trace);
@@ -484,7 +487,7 @@ static int launch_run(ongym_env *env, int mode, int nsteps, const int32_t *d_act
 
 static int ensure_out(ongym_env *env, size_t n) {
     if (env->d_out_n >= n) return 0;
-    if (env->d_out) { hipFree(env->d_out); env->d_out = nullptr; env->d_out_n = 0; }
+    if (env->d_out) { (void)hipFree(env->d_out); env->d_out = nullptr; env->d_out_n = 0; }
     HIP_TRY(env, hipMalloc(reinterpret_cast<void **>(&env->d_out), n * sizeof(ongym_step_rec)));
     env->d_out_n = n;
     return 0;

@@ -67,12 +67,13 @@ typedef struct orc_env {
     double ep_osnr_sum; int64_t ep_services_listed; /* for mean_gsnr: topology.graph["services"] */
     int64_t episodes_completed;
     ongym_stats last; /* snapshot at last terminal step */
-    int64_t total_steps, total_accepted, total_gn, total_terms;
+    int64_t total_steps, total_accepted, total_gn, total_terms, total_paths, total_hops, total_active_sum;
     /* request source */
     int mode;               /* 0 none, 1 rng, 2 trace */
     uint64_t key, req_index;
     const ongym_request *trace; int64_t trace_n, trace_pos;
     int flags;
+    void *scratch_intf; int32_t *scratch_avail;   /* preallocated work buffers */
 } orc_env;
 
 static void *dup_mem(const void *p, size_t n) { void *q = malloc(n ? n : 1); if (p && n) memcpy(q, p, n); return q; }
@@ -107,6 +108,8 @@ orc_env *orc_create(const ongym_config *c, int replica) {
     e->heap = (orc_event *)malloc(sizeof(orc_event) * e->pool_cap);
     e->max_mod_idx = M - 1;
     e->current_time = 0.0;
+    e->scratch_intf = malloc(32 * ((size_t)e->pool_cap + 1) * (size_t)H);
+    e->scratch_avail = (int32_t *)malloc(sizeof(int32_t) * c->n_slots);
     return e;
 }
 
@@ -115,7 +118,7 @@ void orc_destroy(orc_env *e) {
     free(e->pair_paths); free(e->path_hops); free(e->path_links); free(e->link_nspans); free(e->link_span_km);
     free(e->link_alpha); free(e->link_nf); free(e->mod_se); free(e->mod_thr); free(e->bit_rates);
     free(e->bit_rate_cum); free(e->node_cum); free(e->grid); free(e->pool); free(e->pool_free); free(e->run);
-    free(e->run_cnt); free(e->heap); free(e);
+    free(e->run_cnt); free(e->heap); free(e->scratch_intf); free(e->scratch_avail); free(e);
 }
 
 void orc_seed(orc_env *e, uint64_t seed, uint64_t replica) {
@@ -322,7 +325,7 @@ static double center_freq(const orc_env *e, int slot, int n) {
 static void gn_state(orc_env *e, int path_id, int slot, int n, double out[3], int count) {
     int H = e->cfg.max_hops, hops = e->path_hops[path_id];
     const orc_intf *lists[ORC_MAX_HOPS]; int counts[ORC_MAX_HOPS];
-    orc_intf *buf = (orc_intf *)malloc(sizeof(orc_intf) * (size_t)(e->n_running + 1) * hops);
+    orc_intf *buf = (orc_intf *)e->scratch_intf;
     size_t off = 0;
     for (int h = 0; h < hops; h++) {
         int l = e->path_links[path_id * H + h];
@@ -336,7 +339,6 @@ static void gn_state(orc_env *e, int path_id, int slot, int n, double out[3], in
     if (count) e->total_gn++;
     gn_core(e, path_id, center_freq(e, slot, n), e->cfg.slot_bandwidth * n, e->launch_power, -1, lists, counts, out,
             count ? &e->total_terms : 0);
-    free(buf);
 }
 void orc_gn(orc_env *e, int path_id, int slot, int n, double out[3]) { gn_state(e, path_id, slot, n, out, 0); }
 
@@ -381,11 +383,12 @@ int orc_reject_action(const orc_env *e) { return e->cfg.k_paths * e->cfg.n_mods 
 int orc_policy_first_fit(orc_env *e, int *blocked_resources, int *blocked_osnr) {
     int bres = 0, bosnr = 0;
     int S = e->cfg.n_slots, K = e->cfg.k_paths, N = e->cfg.n_nodes;
-    int32_t *avail = (int32_t *)malloc(sizeof(int32_t) * S);
+    int32_t *avail = e->scratch_avail;
     int action = orc_reject_action(e);
     for (int k = 0; k < K; k++) {
         int p = e->pair_paths[(e->cur.src * N + e->cur.dst) * K + k];
         if (p < 0) break;                                          /* fewer than k paths exist */
+        e->total_paths++; e->total_hops += e->path_hops[p];
         for (int m = e->max_mod_idx; m >= 0; m--) {
             int req = orc_number_slots(e, e->cur.bit_rate, m);
             if (req <= 0) continue;
@@ -399,7 +402,6 @@ int orc_policy_first_fit(orc_env *e, int *blocked_resources, int *blocked_osnr) 
             double threshold = e->mod_thr[m] + e->margin;
             if (o[0] >= threshold) {
                 action = orc_encode_action(e, k, m, first);
-                free(avail);
                 *blocked_resources = 0; *blocked_osnr = 0;
                 return action;
             }
@@ -407,7 +409,6 @@ int orc_policy_first_fit(orc_env *e, int *blocked_resources, int *blocked_osnr) 
             if (bres) bres = 0;
         }
     }
-    free(avail);
     *blocked_resources = bres; *blocked_osnr = bosnr;
     return action;
 }
@@ -513,6 +514,7 @@ int orc_step(orc_env *e, int action, ongym_step_rec *out) {
     r.terminated = (uint8_t)(e->ep_processed == e->cfg.episode_length); /* :1056 */
     if (r.terminated) e->episodes_completed++;
     r.active = e->n_running;
+    e->total_active_sum += e->n_running;
     if (out) *out = r;
     return 0;
 }
@@ -528,7 +530,8 @@ void orc_stats(const orc_env *e, ongym_stats *s) {
     memcpy(s->episode_modulation_hist, e->ep_mod_hist, sizeof(e->ep_mod_hist));
     s->episode_osnr_sum = e->ep_osnr_sum; s->episodes_completed = e->episodes_completed;
     s->total_steps = e->total_steps; s->total_accepted = e->total_accepted; s->total_gn_evals = e->total_gn;
-    s->total_interferer_terms = e->total_terms; s->current_time = e->current_time; s->active = e->n_running;
+    s->total_interferer_terms = e->total_terms; s->total_paths_tried = e->total_paths;
+    s->total_path_hops = e->total_hops; s->total_active_sum = e->total_active_sum; s->current_time = e->current_time; s->active = e->n_running;
     s->flags = e->flags;
 }
 
