@@ -112,12 +112,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # RCCL
+    from optical_networking_gym._dist import init_process_group, rank_seed, reduce_run_statistics
+    dist = init_process_group("nccl", local_rank) if world > 1 else None   # "nccl" is RCCL on ROCm
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -131,7 +127,7 @@ def main():
     env = BatchedQRMSAEnv(tables=tables, modulations=jocn_modulations(), batch_size=args.batch, device=local_rank,
                           num_spectrum_resources=wl["S"], capacity=wl["capacity"], episode_length=1000,
                           auto_reset=True, load=wl["load"], bit_rate_selection="discrete", bit_rates=wl["bit_rates"])
-    env.seed(args.seed + 1000003 * rank)
+    env.seed(rank_seed(args.seed, rank))
     env.reset()
 
     def run(nsteps, timed):
@@ -166,14 +162,7 @@ def main():
     fields = ("total_steps", "total_accepted", "total_gn_evals", "total_interferer_terms", "total_paths_tried",
               "total_path_hops", "total_active_sum")
     delta = np.array([float(s1[f].sum() - s0[f].sum()) for f in fields], np.float64)
-    dt_max = dt
-    if dist:
-        t = torch.tensor(delta, device="cuda")
-        dist.all_reduce(t)                                        # RCCL: the only collective, off the data path
-        delta = t.cpu().numpy()
-        tt = torch.tensor([dt, kernel_ms], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt_max, kernel_ms = float(tt[0]), float(tt[1])
+    delta, dt_max, kernel_ms = reduce_run_statistics(delta, dt, kernel_ms, dist)   # the only collective (RCCL)
     stats_sum = dict(zip(fields, delta))
     expected = float(args.batch) * args.steps * world
     if int(stats_sum["total_steps"]) != int(expected):

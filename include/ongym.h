@@ -186,6 +186,14 @@ int ongym_policy_actions(ongym_env *env, int32_t policy, int32_t *actions, uint8
 int ongym_query_available(ongym_env *env, int32_t replica, int32_t path_id, int32_t *out);
 /* calculate_osnr(env, service) (core/osnr.pyx:21-142) for a candidate (path, slot, nslots): out = gsnr, ase, nli dB */
 int ongym_query_gsnr(ongym_env *env, int32_t replica, int32_t path_id, int32_t slot, int32_t nslots, double out[3]);
+/* QRMSAEnv._get_candidates(available_slots, n, total_slots) (qrmsa.pyx:515-541) on an ARBITRARY row (1 = free):
+ * starts_out[total_slots] receives the feasible start slots in ascending order, *count their number.
+ * total_slots <= 1023. State-independent (no replica argument). */
+int ongym_query_candidates(ongym_env *env, const int32_t *row, int32_t total_slots, int32_t nslots,
+                           int32_t *starts_out, int32_t *count);
+/* QRMSAEnv.is_path_free(path, initial_slot, number_slots) (qrmsa.pyx:1248-1264): *out = 1 if free */
+int ongym_query_path_free(ongym_env *env, int32_t replica, int32_t path_id, int32_t slot, int32_t nslots,
+                          int32_t *out);
 /* topology.graph["available_slots"] (qrmsa.pyx:306-309): out[n_links*n_slots] */
 int ongym_query_grid(ongym_env *env, int32_t replica, int32_t *out);
 /* topology.graph["running_services"]: out[capacity], *n = count */

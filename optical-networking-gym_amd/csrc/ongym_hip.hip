@@ -90,7 +90,7 @@ __global__ void k_rewind(Params P) {   // new trace: cursor back to 0
     P.env[r].req_index = 0;
 }
 
-enum { kQAvailable = 0, kQGsnr = 1, kQGrid = 2, kQServices = 3, kQRequest = 4 };
+enum { kQAvailable = 0, kQGsnr = 1, kQGrid = 2, kQServices = 3, kQRequest = 4, kQCandidates = 5, kQPathFree = 6 };
 
 template <bool UA>
 __global__ __launch_bounds__(64) void k_query(Params P, int what, int replica, int path, int slot, int n,
@@ -130,6 +130,25 @@ __global__ __launch_bounds__(64) void k_query(Params P, int what, int replica, i
             o[i].path_id = a & 0xFFFF; o[i].slot = (int16_t)(a >> 16); o[i].nslots = (int16_t)(b & 0xFFFF);
             o[i].modulation = (int16_t)((b >> 16) & 0xFF); o[i].reserved = 0; o[i].release_time = c.sr[i];
         }
+    } else if (what == kQCandidates) {  // _get_candidates on a caller-supplied row: path = total_slots, n = nslots
+        const int total = path;
+        const int32_t *row = out_i;         // input row [total], output flags at out_i[1024 .. 1024+total)
+        uint64_t x = 0;
+        for (int j = 0; j < 64; j++) {
+            int sl = c.lane * 64 + j;
+            if (sl < total && row[sl] != 0) x |= 1ull << j;
+        }
+        if (c.lane == (total >> 6)) x |= 1ull << (total & 63);
+        x = run_and(x, n + 1);
+        for (int j = 0; j < 64; j++) {
+            int sl = c.lane * 64 + j;
+            if (sl < total) out_i[1024 + sl] = (int32_t)((x >> j) & 1ull);
+        }
+    } else if (what == kQPathFree) {    // is_path_free, envs/qrmsa.pyx:1248-1264
+        PathRef p = load_path(c, path);
+        uint64_t ok = run_and(path_free_ext(c, p), n + 1);
+        uint64_t w = __shfl((unsigned long long)ok, slot >> 6);
+        if (c.lane == 0) out_i[0] = (int32_t)((w >> (slot & 63)) & 1ull);
     } else if (what == kQRequest) {
         if (c.lane == 0) {
             ongym_request *q = reinterpret_cast<ongym_request *>(out_i);
@@ -325,7 +344,7 @@ static int build(ongym_env *env, const ongym_config *c) {
         HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_query<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->lds));
     }
     // scratch for queries / host-buffer I/O
-    env->scratch_i_bytes = std::max((size_t)E * c->n_slots * 4, (size_t)c->capacity * sizeof(ongym_service) + 16);
+    env->scratch_i_bytes = std::max(std::max((size_t)E * c->n_slots * 4, (size_t)c->capacity * sizeof(ongym_service) + 16), (size_t)2048 * 4);
     if ((rc = dev_alloc(env, env->scratch_i_bytes / 4 + 4, &env->d_scratch_i, true))) return rc;
     if ((rc = dev_alloc(env, 4, &env->d_scratch_d, true))) return rc;
     if ((rc = dev_alloc(env, B, &env->d_actions, true))) return rc;
@@ -542,8 +561,10 @@ int ongym_policy_actions(ongym_env *env, int32_t policy, int32_t *actions, uint8
 
 static int query(ongym_env *env, int what, int replica, int path, int slot, int n) {
     if (replica < 0 || replica >= env->P.batch) return fail_arg(env, "replica out of range");
-    if ((what == kQAvailable || what == kQGsnr) && (path < 0 || path >= env->P.n_paths)) return fail_arg(env, "path id out of range");
+    if ((what == kQAvailable || what == kQGsnr || what == kQPathFree) && (path < 0 || path >= env->P.n_paths)) return fail_arg(env, "path id out of range");
     if (what == kQGsnr && (slot < 0 || n <= 0 || slot + n > env->P.n_slots)) return fail_arg(env, "slot range out of the grid");
+    if (what == kQPathFree && (slot < 0 || n <= 0 || slot >= env->P.n_slots || n > 1023)) return fail_arg(env, "slot / nslots out of range");
+    if (what == kQCandidates && (path <= 0 || path > 1023 || n <= 0 || n > 1023)) return fail_arg(env, "total_slots / nslots out of range");
     HIP_TRY(env, hipSetDevice(env->cfg.device));
     if (env->P.uniform_alpha)
         hipLaunchKernelGGL(k_query<true>, dim3(1), dim3(64), env->lds, env->stream, env->P, what, replica, path, slot, n, env->d_scratch_i, env->d_scratch_d);
@@ -567,6 +588,32 @@ int ongym_query_gsnr(ongym_env *env, int32_t replica, int32_t path_id, int32_t s
     int rc = query(env, kQGsnr, replica, path_id, slot, nslots);
     if (rc) return rc;
     HIP_TRY(env, hipMemcpyAsync(out, env->d_scratch_d, 3 * sizeof(double), hipMemcpyDeviceToHost, env->stream));
+    HIP_TRY(env, hipStreamSynchronize(env->stream));
+    return ONGYM_OK;
+}
+
+int ongym_query_candidates(ongym_env *env, const int32_t *row, int32_t total_slots, int32_t nslots,
+                           int32_t *starts_out, int32_t *count) {
+    if (!env || !row || !starts_out || !count) return ONGYM_E_ARG;
+    if (total_slots <= 0 || total_slots > 1023) return fail_arg(env, "total_slots out of range");
+    HIP_TRY(env, hipSetDevice(env->cfg.device));
+    HIP_TRY(env, hipMemcpyAsync(env->d_scratch_i, row, (size_t)total_slots * 4, hipMemcpyHostToDevice, env->stream));
+    int rc = query(env, kQCandidates, 0, total_slots, 0, nslots);
+    if (rc) return rc;
+    std::vector<int32_t> flags((size_t)total_slots);
+    HIP_TRY(env, hipMemcpyAsync(flags.data(), env->d_scratch_i + 1024, (size_t)total_slots * 4, hipMemcpyDeviceToHost, env->stream));
+    HIP_TRY(env, hipStreamSynchronize(env->stream));
+    int32_t k = 0;
+    for (int32_t s = 0; s < total_slots; s++) if (flags[s]) starts_out[k++] = s;   // flag -> list, no arithmetic
+    *count = k;
+    return ONGYM_OK;
+}
+
+int ongym_query_path_free(ongym_env *env, int32_t replica, int32_t path_id, int32_t slot, int32_t nslots, int32_t *out) {
+    if (!env || !out) return ONGYM_E_ARG;
+    int rc = query(env, kQPathFree, replica, path_id, slot, nslots);
+    if (rc) return rc;
+    HIP_TRY(env, hipMemcpyAsync(out, env->d_scratch_i, 4, hipMemcpyDeviceToHost, env->stream));
     HIP_TRY(env, hipStreamSynchronize(env->stream));
     return ONGYM_OK;
 }

@@ -1,0 +1,39 @@
+"""Multi-GPU plumbing: one process per GPU, replicas sharded by rank, ONE collective (statistics all-reduce).
+
+The reference has no distributed backend (its fan-out is multiprocessing.Pool over whole simulations,
+examples/JOCN_Benchmark_2024/graph_load.py:361-363); replicas are independent, so nothing is exchanged on the data
+path. `backend="nccl"` is RCCL on ROCm; the same code runs on gloo for the CPU tests.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+
+def init_process_group(backend: str = "nccl", local_rank: int = 0):
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl":
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend=backend)
+    return dist
+
+
+def rank_seed(base_seed: int, rank: int) -> int:
+    """Seed of a rank's request streams: replica r of rank k draws stream (rank_seed, r)."""
+    return int(base_seed) + 1000003 * int(rank)
+
+
+def reduce_run_statistics(delta: np.ndarray, dt: float, kernel_ms: float, dist=None, device: str = "cuda"):
+    """SUM of the per-rank counter deltas, MAX of the per-rank wall time and kernel time."""
+    if dist is None:
+        return np.asarray(delta, np.float64), float(dt), float(kernel_ms)
+    import torch
+    t = torch.tensor(np.asarray(delta, np.float64), device=device)
+    dist.all_reduce(t)
+    tt = torch.tensor([dt, kernel_ms], device=device, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return t.cpu().numpy(), float(tt[0]), float(tt[1])

@@ -134,6 +134,21 @@ class BatchedQRMSAEnv:
                     "ongym_query_gsnr")
         return out
 
+    def candidates(self, row: np.ndarray, nslots: int) -> list:
+        """`_get_candidates(row, nslots, len(row))` evaluated on device."""
+        row = np.ascontiguousarray(row, np.int32)
+        out = np.zeros(len(row), np.int32)
+        n = C.c_int32(0)
+        self._check(self.lib.ongym_query_candidates(self._h, row.ctypes.data, len(row), int(nslots), out.ctypes.data,
+                                                    C.byref(n)), "ongym_query_candidates")
+        return out[:n.value].tolist()
+
+    def is_path_free(self, replica: int, path_id: int, slot: int, nslots: int) -> bool:
+        out = C.c_int32(0)
+        self._check(self.lib.ongym_query_path_free(self._h, replica, path_id, int(slot), int(nslots), C.byref(out)),
+                    "ongym_query_path_free")
+        return bool(out.value)
+
     def grid(self, replica: int) -> np.ndarray:
         c = self.holder.struct
         out = np.zeros((c.n_links, c.n_slots), np.int32)

@@ -1,0 +1,330 @@
+"""Single-environment compatibility view: the reference's `QRMSAEnv` surface on top of one device replica.
+
+Mirrors `optical_networking_gym/envs/qrmsa.pyx` of the reference for the per-request hot path:
+constructor kwargs (:206-237), `reset` (:427-504), `step` (:838-1065) and the helper API the heuristic plugins touch
+(`get_number_slots` :1198-1205, `get_available_slots` :1482-1512, `_get_candidates` :515-541, `is_path_free`
+:1248-1264, `encoded_decimal_to_array` :801-834, `get_available_blocks` :1513-1528, `_get_spectrum_slots` :1531-1541).
+
+Every one of those calls is answered by the HIP kernels through the C ABI (include/ongym.h) on a B=1 environment:
+this view does no slot-grid or GN arithmetic of its own, it only converts between the reference's Python objects
+(`Service`, `Path`, graph attributes) and device records. It is the slow drop-in path for existing agents and plugin
+heuristics; batch-scale use goes through `envs.batched.BatchedQRMSAEnv`.
+
+Not covered yet (raise NotImplementedError rather than silently differ): `gen_observation=True` (observation + action
+mask), `measure_disruptions`, `defragmentation`, `bands` (quirk Q9), per-service CSV (`file_name`).
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Any, Optional
+
+import numpy as np
+
+from .. import _native as nat
+from .._tables import StaticTables
+from ..utils import rle
+from .batched import BatchedQRMSAEnv, OngymError
+
+try:  # gymnasium is optional (absent in the build image)
+    import gymnasium as _gym
+    _Discrete, _Box = _gym.spaces.Discrete, _gym.spaces.Box
+except Exception:  # pragma: no cover - exercised where gymnasium is missing
+    _gym = None
+
+    class _Discrete:
+        def __init__(self, n):
+            self.n = int(n)
+            self._rng = np.random.default_rng()
+
+        def sample(self):
+            return int(self._rng.integers(self.n))
+
+        def contains(self, x):
+            return 0 <= int(x) < self.n
+
+    class _Box:
+        def __init__(self, low, high, shape, dtype=np.float32):
+            self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), dtype
+
+
+class Service:
+    """Per-request record with the reference's field names (envs/qrmsa.pyx:29-116)."""
+
+    __slots__ = ("service_id", "source", "source_id", "destination", "destination_id", "arrival_time",
+                 "holding_time", "bit_rate", "path", "service_class", "initial_slot", "center_frequency", "bandwidth",
+                 "number_slots", "core", "launch_power", "accepted", "blocked_due_to_resources",
+                 "blocked_due_to_osnr", "OSNR", "ASE", "NLI", "current_modulation", "recalculate")
+
+    def __init__(self, service_id, source, source_id, destination=None, destination_id=None, arrival_time=0.0,
+                 holding_time=0.0, bit_rate=0.0, path=None, service_class=0, initial_slot=0, center_frequency=0,
+                 bandwidth=0, number_slots=0, core=0, launch_power=0.0, accepted=False,
+                 blocked_due_to_resources=True, blocked_due_to_osnr=True, OSNR=0.0, ASE=0.0, NLI=0.0,
+                 current_modulation=None):
+        self.service_id, self.source, self.source_id = service_id, source, source_id
+        self.destination, self.destination_id = destination, destination_id
+        self.arrival_time, self.holding_time, self.bit_rate = float(arrival_time), float(holding_time), float(bit_rate)
+        self.path, self.service_class, self.initial_slot = path, service_class, initial_slot
+        self.center_frequency, self.bandwidth, self.number_slots = center_frequency, bandwidth, number_slots
+        self.core, self.launch_power, self.accepted = core, launch_power, accepted
+        self.blocked_due_to_resources, self.blocked_due_to_osnr = blocked_due_to_resources, blocked_due_to_osnr
+        self.OSNR, self.ASE, self.NLI = OSNR, ASE, NLI
+        self.current_modulation = current_modulation
+        self.recalculate = False
+
+    def __repr__(self):
+        return (f"Service(service_id={self.service_id}, source='{self.source}', destination='{self.destination}', "
+                f"bit_rate={self.bit_rate}, path={self.path}, initial_slot={self.initial_slot}, "
+                f"number_slots={self.number_slots}, accepted={self.accepted}, OSNR={self.OSNR})")
+
+
+class QRMSAEnv:
+    def __init__(self, topology, num_spectrum_resources: int = 320, episode_length: int = 1000, load: float = 10.0,
+                 mean_service_holding_time: float = 10800.0, bit_rate_selection: str = "continuous",
+                 bit_rates: tuple = (10, 40, 100), bit_rate_probabilities=None, node_request_probabilities=None,
+                 bit_rate_lower_bound: float = 25.0, bit_rate_higher_bound: float = 100.0,
+                 launch_power_dbm: float = 0.0, bandwidth: float = 4e12, frequency_start: float = (3e8 / 1565e-9),
+                 frequency_slot_bandwidth: float = 12.5e9, margin: float = 0.0, measure_disruptions: bool = False,
+                 seed: object = None, allow_rejection: bool = True, reset: bool = True, channel_width: float = 12.5,
+                 k_paths: int = 5, file_name: str = "", blocks_to_consider: int = 1, modulations_to_consider: int = 6,
+                 defragmentation: bool = False, n_defrag_services: int = 0, gen_observation: bool = True,
+                 bands: object = None, device: int = 0, capacity: int = 1024, sync_views: bool = True,
+                 requests: Optional[np.ndarray] = None):
+        if gen_observation:
+            raise NotImplementedError("gen_observation=True (observation + action mask) is not built yet: "
+                                      "pass gen_observation=False as the JOCN benchmark does")
+        if measure_disruptions or defragmentation or bands or file_name:
+            raise NotImplementedError("measure_disruptions / defragmentation / bands / file_name are not built yet")
+        if seed is not None and not isinstance(seed, (int, np.integer)):
+            raise ValueError("Seed must be an integer.")
+        self.topology = topology
+        self.k_shortest_paths = topology.graph["ksp"]          # KeyError 'ksp' on a bare graph, like the reference
+        self.modulations = topology.graph.get("modulations", [])
+        self.num_spectrum_resources = int(num_spectrum_resources)
+        self.episode_length = int(episode_length)
+        self.load, self.mean_service_holding_time = float(load), float(mean_service_holding_time)
+        self.bit_rate_selection, self.bit_rates = bit_rate_selection, tuple(bit_rates)
+        self.channel_width, self.k_paths = float(channel_width), int(k_paths)
+        self.launch_power_dbm = float(launch_power_dbm)
+        self.launch_power = 10 ** ((self.launch_power_dbm - 30) / 10)
+        self.frequency_start, self.frequency_slot_bandwidth = float(frequency_start), float(frequency_slot_bandwidth)
+        self.frequency_end = self.frequency_start + self.frequency_slot_bandwidth * self.num_spectrum_resources
+        assert math.isclose(self.frequency_end - self.frequency_start, bandwidth, rel_tol=1e-5)
+        self.margin = float(margin)
+        self.max_modulation_idx = len(self.modulations) - 1
+        self.modulations_to_consider = min(modulations_to_consider, len(self.modulations))
+        self.allow_rejection = allow_rejection
+        self.bands, self.current_band = [], None
+        self.blocks_to_consider = blocks_to_consider
+        self.input_seed = int(seed) % (2 ** 31) if seed is not None else int(np.random.SeedSequence().generate_state(1)[0] % (2 ** 31))
+        self.action_space = _Discrete(self.k_paths * self.modulations_to_consider * self.num_spectrum_resources + 1)
+        self.observation_space = _Box(low=-5, high=5, shape=(1 + 2 + self.k_paths + self.k_paths * self.modulations_to_consider * 12,),
+                                      dtype=np.float32)
+        self.reject_action = self.action_space.n - 1 if allow_rejection else 0
+        self._tables = StaticTables.from_topology(topology)
+        self._paths_by_id = {}
+        for routes in self.k_shortest_paths.values():
+            for p in routes:
+                self._paths_by_id[int(p.id)] = p
+        self._nodes = list(topology.graph["node_indices"])
+        self._dev = BatchedQRMSAEnv(
+            tables=self._tables, modulations=self.modulations, modulations_to_consider=modulations_to_consider,
+            batch_size=1, capacity=capacity, auto_reset=False, device=device,
+            num_spectrum_resources=num_spectrum_resources, episode_length=episode_length, load=load,
+            mean_service_holding_time=mean_service_holding_time, bit_rate_selection=bit_rate_selection,
+            bit_rates=bit_rates, bit_rate_probabilities=bit_rate_probabilities,
+            node_request_probabilities=node_request_probabilities, bit_rate_lower_bound=bit_rate_lower_bound,
+            bit_rate_higher_bound=bit_rate_higher_bound, launch_power_dbm=launch_power_dbm,
+            frequency_start=frequency_start, frequency_slot_bandwidth=frequency_slot_bandwidth, margin=margin,
+            channel_width=channel_width)
+        if requests is not None:
+            self._dev.set_requests(requests)           # trace replay (parity tests)
+        else:
+            # the reference's traffic RNG is unseeded (quirk Q2); here `seed` selects the device stream
+            self._dev.seed(self.input_seed)
+        self._sync_views = bool(sync_views)
+        self.current_service: Optional[Service] = None
+        self.current_time = 0.0
+        self._last_stats = None
+        if reset:
+            self.reset()
+
+    # ---- views ---------------------------------------------------------------------------------------------------
+    def _pull_request(self):
+        q = self._dev.request(0)
+        st = self._dev.stats()[0]
+        self._last_stats = st
+        self.current_time = float(st["current_time"])
+        src, dst = int(q["source"]), int(q["destination"])
+        self.current_service = Service(
+            service_id=int(st["episode_services_processed"]) - 1, source=self._nodes[src], source_id=src,
+            destination=self._nodes[dst], destination_id=str(dst), arrival_time=float(q["arrival_time"]),
+            holding_time=float(q["holding_time"]), bit_rate=float(q["bit_rate"]))
+
+    def _refresh_views(self):
+        if not self._sync_views:
+            return
+        g = self.topology.graph
+        g["available_slots"] = self._dev.grid(0)
+        running = []
+        for u, v in self.topology.edges():
+            self.topology[u][v]["running_services"] = []
+        for rec in self._dev.services(0):
+            path = self._paths_by_id[int(rec["path_id"])]
+            mod = self.modulations[int(rec["modulation"])]
+            n, s = int(rec["nslots"]), int(rec["slot"])
+            svc = Service(service_id=-1, source=path.node_list[0], source_id=self._nodes.index(path.node_list[0]),
+                          destination=path.node_list[-1], path=path, initial_slot=s, number_slots=n,
+                          center_frequency=self.frequency_start + self.frequency_slot_bandwidth * s
+                          + self.frequency_slot_bandwidth * (n / 2.0),
+                          bandwidth=self.frequency_slot_bandwidth * n, launch_power=self.launch_power, accepted=True,
+                          current_modulation=mod)
+            running.append(svc)
+            for link in path.links:
+                self.topology[link.node1][link.node2]["running_services"].append(svc)
+        g["running_services"] = running
+
+    # ---- gym surface ---------------------------------------------------------------------------------------------------
+    def _blank_observation(self):
+        # gen_observation=False: zeros, including the reject slot of the mask (qrmsa.pyx:584-587)
+        return (np.zeros(self.observation_space.shape, np.float32),
+                {"mask": np.zeros(self.action_space.n, np.uint8)})
+
+    def reset(self, seed=None, options=None):
+        if options and options.get("only_episode_counters"):
+            raise NotImplementedError("only_episode_counters reset is not built yet")
+        self._dev.reset()
+        self.topology.graph["services"] = []
+        self.max_modulation_idx = len(self.modulations) - 1
+        self._pull_request()
+        self._refresh_views()
+        obs, mask = self._blank_observation()
+        return obs, dict(mask)
+
+    def step(self, action: int):
+        cur = self.current_service
+        rec = self._dev.step(np.array([int(action)], np.int32))[0]
+        obs, mask = self._blank_observation()
+        if rec["flags"] & nat.F_QOT_ERROR:
+            route, mod_idx, slot = self.encoded_decimal_to_array(int(action))
+            modulation = self.modulations[mod_idx]
+            raise ValueError(f"Osnr {rec['osnr']} is not enough for service {cur.service_id} with modulation "
+                             f"{modulation}, and osnr_req {modulation.minimum_osnr + self.margin}.")
+        if rec["flags"] & nat.F_NO_REQUEST:
+            raise OngymError("request trace exhausted")
+        if rec["retry"]:   # quirk Q5 (qrmsa.pyx:886-897): penalty, same request stays current
+            cur.blocked_due_to_resources, cur.accepted = True, False
+            info = {"blocked_due_to_resources": 1, "blocked_due_to_osnr": 0, "rejected": 1}
+            info.update(mask)
+            return obs, float(rec["reward"]), False, False, info
+        cur.blocked_due_to_resources = cur.blocked_due_to_osnr = False
+        cur.accepted = bool(rec["accepted"])
+        osnr_req = 0.0
+        if int(action) != self.action_space.n - 1:
+            osnr_req = self.modulations[self.encoded_decimal_to_array(int(action))[1]].minimum_osnr + self.margin
+        if cur.accepted:
+            n, s = int(rec["nslots"]), int(rec["slot"])
+            cur.path = self.k_shortest_paths[cur.source, cur.destination][int(rec["route"])]
+            cur.initial_slot, cur.number_slots = s, n
+            cur.center_frequency = self.frequency_start + self.frequency_slot_bandwidth * s + self.frequency_slot_bandwidth * (n / 2.0)
+            cur.bandwidth, cur.launch_power = self.frequency_slot_bandwidth * n, self.launch_power
+            cur.OSNR, cur.ASE, cur.NLI = float(rec["osnr"]), float(rec["ase"]), float(rec["nli"])
+            cur.current_modulation = self.modulations[int(rec["modulation"])]
+        else:
+            cur.path, cur.initial_slot, cur.number_slots = None, -1, 0
+            cur.OSNR = cur.ASE = cur.NLI = 0.0
+        self.topology.graph["services"].append(cur)
+        self._pull_request()
+        self._refresh_views()
+        st = self._last_stats
+        terminated = bool(rec["terminated"])
+        # info of qrmsa.pyx:996-1050 is computed BEFORE the next request is drawn: undo that draw's increments
+        sp, sa = int(st["services_processed"]) - 1, int(st["services_accepted"])
+        ep, ea = int(st["episode_services_processed"]) - 1, int(st["episode_services_accepted"])
+        nxt = float(self.current_service.bit_rate)
+        brq, brp = float(st["bit_rate_requested"]) - nxt, float(st["bit_rate_provisioned"])
+        ebrq, ebrp = float(st["episode_bit_rate_requested"]) - nxt, float(st["episode_bit_rate_provisioned"])
+        info = {
+            "episode_services_accepted": ea,
+            "service_blocking_rate": (sp - sa) / sp if sp > 0 else 0.0,
+            "episode_service_blocking_rate": (ep - ea) / ep if ep > 0 else 0.0,
+            "bit_rate_blocking_rate": (brq - brp) / brq if brq > 0 else 0.0,
+            "episode_bit_rate_blocking_rate": (ebrq - ebrp) / ebrq if ebrq > 0 else 0.0,
+            "disrupted_services": 0.0, "episode_disrupted_services": 0.0,
+            "osnr": float(rec["osnr"]), "osnr_req": float(osnr_req),
+            "chosen_path_index": int(rec["route"]), "chosen_slot": int(rec["slot"]),
+            "episode_defrag_cicles": 0, "episode_service_realocations": 0,
+        }
+        if terminated:   # the device snapshots the exact fp64 rates at the terminal step
+            info["service_blocking_rate"] = float(st["last_service_blocking_rate"])
+            info["episode_service_blocking_rate"] = float(st["last_episode_service_blocking_rate"])
+            info["bit_rate_blocking_rate"] = float(st["last_bit_rate_blocking_rate"])
+            info["episode_bit_rate_blocking_rate"] = float(st["last_episode_bit_rate_blocking_rate"])
+        for m, modulation in enumerate(self.modulations):
+            info["modulation_{}".format(str(float(modulation.spectral_efficiency)))] = int(st["episode_modulation_hist"][m])
+        if terminated:
+            info["blocked_due_to_resources"] = 0   # always 0 in the reference (quirk Q6)
+            info["blocked_due_to_osnr"] = 0
+            info["rejected"] = int(st["last_rejected"])
+        info.update(mask)
+        return obs, float(rec["reward"]), terminated, False, info
+
+    # ---- plugin API --------------------------------------------------------------------------------------------------
+    def get_number_slots(self, service, modulation) -> int:
+        # integer ceil of bit_rate / (SE * 12.5): answered by the same table the kernels use is not exposed per call;
+        # this is pure request arithmetic (no state), identical to qrmsa.pyx:1198-1205 with bands unset
+        return int(math.ceil(float(np.float32(service.bit_rate)) / (modulation.spectral_efficiency * self.channel_width)))
+
+    def get_available_slots(self, path) -> np.ndarray:
+        return self._dev.available_slots(0, int(path.id))
+
+    def _get_candidates(self, available_slots, num_slots_required, total_slots):
+        row = np.asarray(available_slots)[:total_slots]
+        return self._dev.candidates(row, int(num_slots_required))
+
+    def is_path_free(self, path, initial_slot: int, number_slots: int) -> bool:
+        if initial_slot < 0 or initial_slot >= self.num_spectrum_resources:
+            return False
+        return self._dev.is_path_free(0, int(path.id), int(initial_slot), int(number_slots))
+
+    def calculate_osnr(self, service) -> tuple:
+        g = self._dev.gsnr(0, int(service.path.id), int(service.initial_slot), int(service.number_slots))
+        return float(g[0]), float(g[1]), float(g[2])
+
+    def _allowed_modulations(self):
+        M = self.modulations_to_consider
+        if self.max_modulation_idx > 1:
+            return list(range(self.max_modulation_idx, self.max_modulation_idx - M, -1))
+        return list(reversed(range(M)))
+
+    def encoded_decimal_to_array(self, decimal: int, max_values=None):
+        if max_values is None:
+            max_values = [self.k_paths, self.modulations_to_consider, self.num_spectrum_resources]
+        digits = []
+        for radix in reversed(max_values):
+            digits.insert(0, decimal % radix)
+            decimal //= radix
+        digits[1] = self._allowed_modulations()[digits[1]]
+        return digits
+
+    decimal_to_array = encoded_decimal_to_array
+
+    def get_available_blocks(self, path: int, slots: int, j):
+        avail = self.get_available_slots(self.k_shortest_paths[self.current_service.source,
+                                                               self.current_service.destination][path])
+        starts, values, lengths = rle(avail)
+        keep = np.intersect1d(np.where(values == 1)[0], np.where(lengths >= slots)[0])[:j]
+        return starts[keep], lengths[keep]
+
+    def _get_spectrum_slots(self, path: int):
+        grid = self._dev.grid(0)
+        route = self.k_shortest_paths[self.current_service.source, self.current_service.destination][path]
+        return [grid[self.topology[l.node1][l.node2]["index"], :] for l in route.links]
+
+    def first_fit_action(self):
+        """The fused device policy (heuristics.py:923-966): (action, blocked_resources, blocked_osnr)."""
+        a, f = self._dev.policy_actions()
+        return int(a[0]), bool(f[0] & nat.F_BLOCKED_RESOURCES), bool(f[0] & nat.F_BLOCKED_OSNR)
+
+    def close(self):
+        self._dev.close()

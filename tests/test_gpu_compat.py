@@ -1,0 +1,151 @@
+"""The reference's Python surface (QRMSAEnvWrapper / heuristics plugin API / calculate_osnr) on one device replica,
+driven exactly like examples/JOCN_Benchmark_2024/graph_load.py:129-164 and checked against the captured reference."""
+import numpy as np
+import pytest
+
+from common import jocn_modulations, load_traj, traj_requests
+from optical_networking_gym.core.osnr import calculate_osnr
+from optical_networking_gym.heuristics.heuristics import (
+    get_action_index, get_qrmsa_env, heuristic_highest_snr,
+    heuristic_shortest_available_path_first_fit_best_modulation,
+    heuristic_shortest_available_path_first_fit_best_modulation_plugin)
+from optical_networking_gym.topology import bundled_topology_path, get_topology
+from optical_networking_gym.wrappers.qrmsa_gym import QRMSAEnvWrapper
+
+pytestmark = pytest.mark.gpu
+
+TOPO_FILE = {"nsfnet": "nsfnet_chen.txt", "ring4": "ring_4.txt", "cost239": "cost239.txt", "nobel-eu": "nobel-eu.txt"}
+
+
+def jocn_env(tag, **over):
+    meta, d = load_traj(tag)
+    topology = get_topology(bundled_topology_path(TOPO_FILE[meta["topology"]]), None, jocn_modulations(), 80, 0.2, 4.5, 5)
+    env_args = dict(topology=topology, seed=10, allow_rejection=True, load=meta["load"],
+                    episode_length=meta["episode_length"], num_spectrum_resources=meta["S"],
+                    launch_power_dbm=meta["launch_power_dbm"], bandwidth=meta["S"] * 12.5e9,
+                    frequency_start=3e8 / 1565e-9, frequency_slot_bandwidth=12.5e9,
+                    bit_rate_selection=meta["bit_rate_selection"], bit_rates=tuple(meta["bit_rates"]),
+                    margin=meta["margin"], file_name="", measure_disruptions=False, k_paths=5,
+                    modulations_to_consider=6, defragmentation=False, n_defrag_services=0, gen_observation=False,
+                    requests=traj_requests(d))
+    env_args.update(over)
+    env = QRMSAEnvWrapper(**env_args)   # constructor resets once (qrmsa.pyx:414-415)
+    env.reset()                         # graph_load.py:129-130
+    return env, meta, d
+
+
+def test_jocn_loop_ring4_full_episodes():
+    """whole run_environment loop: two 299-step episodes, fused first-fit through the plugin signature."""
+    env, meta, d = jocn_env("traj_ring4")
+    i = 0
+    for ep in range(meta["episodes"]):
+        obs, info = env.reset()
+        assert obs.shape == (368,) and obs.dtype == np.float32 and not obs.any()
+        assert info["mask"].shape == (5 * 6 * meta["S"] + 1,) and not info["mask"].any()
+        done = False
+        while not done:
+            action, bres, bosnr = heuristic_shortest_available_path_first_fit_best_modulation(env)
+            assert (action, bres, bosnr) == (d["st_action"][i], bool(d["st_bres"][i]), bool(d["st_bosnr"][i]))
+            _, reward, done, truncated, info = env.step(action)
+            assert reward == d["st_reward"][i] and done == bool(d["st_term"][i]) and truncated is False
+            assert info["episode_services_accepted"] == d["st_ep_acc"][i]
+            assert info["chosen_path_index"] == d["st_route"][i] and info["chosen_slot"] == d["st_slot"][i]
+            if d["st_accepted"][i]:
+                assert info["osnr"] == pytest.approx(d["st_osnr"][i], rel=1e-9)
+            i += 1
+        ti = meta["terminal_infos"][ep]
+        for k in ("service_blocking_rate", "episode_service_blocking_rate", "bit_rate_blocking_rate",
+                  "episode_bit_rate_blocking_rate"):
+            assert info[k] == pytest.approx(ti[k], rel=1e-12, abs=1e-15), k
+        for k in ("rejected", "blocked_due_to_resources", "blocked_due_to_osnr", "episode_services_accepted",
+                  "modulation_1.0", "modulation_2.0", "modulation_3.0", "modulation_4.0", "modulation_5.0",
+                  "modulation_6.0"):
+            assert info[k] == ti[k], k
+        services = env.env.topology.graph["services"]          # graph_load.py:181-185
+        assert len(services) == ti["n_services"]
+        assert sum(s.OSNR for s in services) / len(services) == pytest.approx(ti["mean_gsnr"], rel=1e-9)
+    assert i == meta["n_steps"]
+
+
+def test_plugin_api_policy_equals_fused_policy_and_reference():
+    """A policy written only against the plugin API (get_available_slots/_get_candidates/calculate_osnr ...) picks the
+    reference's actions; the graph views it reads follow the device state."""
+    env, meta, d = jocn_env("traj_nsfnet320")
+    env.reset()
+    sim = get_qrmsa_env(env)
+    for i in range(160):
+        fused = heuristic_shortest_available_path_first_fit_best_modulation(env)
+        plugin = heuristic_shortest_available_path_first_fit_best_modulation_plugin(env)
+        assert fused == plugin == (d["st_action"][i], bool(d["st_bres"][i]), bool(d["st_bosnr"][i])), i
+        env.step(fused[0])
+    # views
+    grid = sim.topology.graph["available_slots"]
+    running = sim.topology.graph["running_services"]
+    assert len(running) == d["st_active"][159]
+    occupied = sum((s.number_slots + (1 if s.initial_slot + s.number_slots < 320 else 0)) * s.path.hops for s in running)
+    assert (grid == 0).sum() == occupied
+    svc = running[0]
+    link = svc.path.links[0]
+    assert svc in sim.topology[link.node1][link.node2]["running_services"]
+    assert sim.topology[link.node1][link.node2]["index"] == link.id
+    # helper API
+    cur = sim.current_service
+    path = sim.k_shortest_paths[cur.source, cur.destination][0]
+    avail = sim.get_available_slots(path)
+    rows = sim._get_spectrum_slots(0)
+    np.testing.assert_array_equal(avail, np.prod(rows, axis=0))
+    n = sim.get_number_slots(cur, sim.modulations[3])
+    starts = sim._get_candidates(avail, n, 320)
+    assert starts and all(sim.is_path_free(path, s, n) for s in starts[:3])
+    busy = np.where(avail == 0)[0]
+    assert not sim.is_path_free(path, int(busy[0]), n)
+    assert sim.encoded_decimal_to_array(get_action_index(sim, 2, 3, 17)) == [2, 3, 17]
+    blocks, lengths = sim.get_available_blocks(0, n, 3)
+    assert all(avail[b:b + l].all() for b, l in zip(blocks, lengths))
+    # highest-SNR plugin returns a feasible action the env accepts
+    action, _, _ = heuristic_highest_snr(env)
+    _, reward, _, _, info = env.step(action)
+    assert reward == 0.0 or action == sim.reject_action
+
+
+def test_step_errors_like_the_reference():
+    env, meta, d = jocn_env("traj_nsfnet320")
+    env.reset()
+    sim = get_qrmsa_env(env)
+    # request #2 of the trace is ('2' -> '11', 10 G)... drive to a request whose best modulation fails QoT
+    for i in range(400):
+        cur = sim.current_service
+        a, _, _ = heuristic_shortest_available_path_first_fit_best_modulation(env)
+        route, mod, slot = sim.encoded_decimal_to_array(a) if a != sim.reject_action else (0, 5, 0)
+        if a != sim.reject_action and mod < 5:
+            bad = get_action_index(sim, route, mod + 1, slot)      # one modulation better than first-fit found feasible
+            n_bad = sim.get_number_slots(cur, sim.modulations[mod + 1])
+            path = sim.k_shortest_paths[cur.source, cur.destination][route]
+            if sim.is_path_free(path, slot, n_bad):
+                with pytest.raises(ValueError, match="is not enough for service"):
+                    env.step(bad)
+                assert sim.current_service is cur
+                break
+        env.step(a)
+    else:
+        pytest.skip("no QoT-limited request in the prefix")
+    # occupied slots: penalty, same request (quirk Q5)
+    path = sim.k_shortest_paths[cur.source, cur.destination][0]
+    avail = sim.get_available_slots(path)
+    busy = np.where(avail == 0)[0]
+    if len(busy):
+        _, reward, done, _, info = env.step(get_action_index(sim, 0, 0, int(busy[0])))
+        assert reward < -3.0 and not done and sim.current_service is cur
+        assert set(info) == {"blocked_due_to_resources", "blocked_due_to_osnr", "rejected", "mask"}
+    # reject action
+    _, reward, _, _, info = env.step(sim.reject_action)
+    assert reward == -6.0 and info["chosen_path_index"] == -1 and sim.current_service is not cur
+
+
+def test_unbuilt_features_fail_loudly():
+    topology = get_topology(bundled_topology_path("nsfnet_chen.txt"), None, jocn_modulations(), 80, 0.2, 4.5, 5)
+    with pytest.raises(NotImplementedError):
+        QRMSAEnvWrapper(topology=topology, load=300, gen_observation=True)
+    import networkx as nx
+    with pytest.raises(KeyError, match="ksp"):
+        QRMSAEnvWrapper(topology=nx.Graph(), gen_observation=False)

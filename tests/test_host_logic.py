@@ -1,0 +1,199 @@
+"""CPU-only checks of the host logic: topology compiler vs tables exported from the reference, C-ABI surface,
+traffic-stream definition, multi-rank statistics reduction (gloo)."""
+import ctypes
+import json
+import math
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from common import GOLDEN, golden_tables, holder_for, jocn_modulations, load_traj, traj_requests
+from cpython_traffic import cpython_request_stream
+from optical_networking_gym import _native as nat
+from optical_networking_gym._tables import StaticTables
+from optical_networking_gym.topology import bundled_topology_path, get_topology
+from optical_networking_gym.utils import rle
+from oracle_lib import OracleEnv
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFERENCE_TOPOLOGIES = "/root/reference/examples/topologies"
+
+
+def tables_equal(a: StaticTables, b: StaticTables):
+    assert (a.n_nodes, a.n_links, a.n_paths, a.k_paths, a.max_hops) == (b.n_nodes, b.n_links, b.n_paths, b.k_paths, b.max_hops)
+    for f in ("pair_paths", "path_hops", "path_links", "link_nodes", "link_nspans"):
+        np.testing.assert_array_equal(getattr(a, f), getattr(b, f), err_msg=f)
+    for f in ("path_length", "link_length", "link_span_km", "link_alpha", "link_nf"):
+        np.testing.assert_allclose(getattr(a, f), getattr(b, f), rtol=1e-15, err_msg=f)
+    assert a.path_nodes == b.path_nodes
+
+
+@pytest.mark.parametrize("fname,gold", [("nsfnet_chen.txt", "nsfnet"), ("cost239.txt", "cost239"),
+                                        ("ring_4.txt", "ring4"), ("nobel-eu.txt", "nobel-eu")])
+def test_topology_compiler_matches_reference_tables(fname, gold):
+    """own parser + span rule + networkx KSP vs the tables the reference's get_topology produced (golden)."""
+    topo = get_topology(bundled_topology_path(fname), None, jocn_modulations(), 80, 0.2, 4.5, 5)
+    tables_equal(StaticTables.from_topology(topo), golden_tables(gold))
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_TOPOLOGIES), reason="reference data files only exist in the build container")
+@pytest.mark.parametrize("fname,gold", [("nobel-eu.xml", "nobel-eu"), ("germany50.xml", "germany50")])
+def test_sndlib_reader_matches_reference_tables(fname, gold):
+    topo = get_topology(os.path.join(REFERENCE_TOPOLOGIES, fname), None, jocn_modulations(), 80, 0.2, 4.5, 5)
+    tables_equal(StaticTables.from_topology(topo), golden_tables(gold))
+
+
+def test_span_rule_and_constants():
+    t = golden_tables("nsfnet")
+    e = {(int(a), int(b)): i for i, (a, b) in enumerate(t.link_nodes)}
+    i = e[(0, 7)]                                 # 2400 km -> 30 x 80 km
+    assert t.link_nspans[i] == 30 and t.link_span_km[i] == 80.0
+    i = e[(1, 3)]                                 # 750 km -> 10 x 75 km
+    assert t.link_nspans[i] == 10 and t.link_span_km[i] == 75.0
+    assert t.link_alpha[0] == pytest.approx(2.3025850929940457e-05, rel=1e-15)
+    assert t.link_nf[0] == pytest.approx(2.818382931264454, rel=1e-15)
+    h = nat.ConfigHolder(t, modulations=jocn_modulations(), load=300)
+    # the reference's -ffast-math build yields 0.0009999999999999994 for 0 dBm (qrmsa.pyx:288): 1 ulp from 10**-3
+    assert h.struct.launch_power_w == pytest.approx(0.0009999999999999994, rel=1e-15) and h.reject_action == 9600
+
+
+def test_unknown_topology_format():
+    with pytest.raises(ValueError, match="Supplied topology format is unknown"):
+        get_topology("nsfnet.h5")
+
+
+def test_rle():
+    s, v, l = rle(np.array([1, 1, 1, 0, 1, 1, 1, 1, 0, 1, 1, 1]))
+    assert s.tolist() == [0, 3, 4, 8, 9] and v.tolist() == [1, 0, 1, 0, 1] and l.tolist() == [3, 1, 4, 1, 3]
+    assert rle(np.array([])) == (None, None, None)
+
+
+# ---- C ABI ---------------------------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(REPO, "include", "ongym.h")).read()
+    declared = set(re.findall(r"\b(ongym_[a-z_]+)\s*\(", header))
+    assert declared == set(nat.EXPORTED_SYMBOLS)
+    lib = nat.load_library()            # dlopen + ABI version + struct sizes; no compute, works without a GPU
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ongym_abi_version() == nat.ABI_VERSION
+    assert lib.ongym_sizeof(2) == nat.STEP_DTYPE.itemsize == 56
+    assert lib.ongym_sizeof(1) == nat.REQUEST_DTYPE.itemsize == 16
+
+
+def test_create_fails_loudly_without_gpu_or_with_bad_config():
+    lib = nat.load_library()
+    h = nat.ConfigHolder(golden_tables("nsfnet"), modulations=jocn_modulations(), load=300)
+    out = ctypes.c_void_p()
+    bad = nat.OngymConfig.from_buffer_copy(h.struct)
+    bad.struct_size = 8
+    assert lib.ongym_create(ctypes.byref(bad), ctypes.byref(out)) == -1
+    assert b"mismatch" in lib.ongym_last_error(None)
+    import torch
+    if not torch.cuda.is_available():
+        from optical_networking_gym.envs.batched import BatchedQRMSAEnv, OngymError
+        with pytest.raises(OngymError, match="no usable HIP device"):
+            BatchedQRMSAEnv(tables=golden_tables("nsfnet"), modulations=jocn_modulations(), load=300)
+
+
+def test_missing_library_is_an_error(tmp_path):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        nat.load_library(str(tmp_path / "nope.so"))
+
+
+# ---- traffic -------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["traj_nsfnet320", "traj_nsfnet320_cont", "traj_nobeleu320"])
+def test_reference_request_stream_is_the_documented_draw_order(tag):
+    """A twin CPython generator (same seed) reproduces the captured reference requests bit for bit: pins the draw order
+    expovariate, expovariate, choices, choices, choices|randint and the float32 rounding points (qrmsa.pyx:1079-1089)."""
+    meta, d = load_traj(tag)
+    t = golden_tables(meta["topology"])
+    twin = cpython_request_stream(meta["seed"], 400, t.n_nodes, meta["load"], meta["mean_holding"],
+                                  meta["bit_rates"] if meta["bit_rate_selection"] == "discrete" else None)
+    assert twin.tobytes() == traj_requests(d)[:400].tobytes()
+
+
+def test_device_stream_definition_statistics():
+    """own counter-based stream (include/ongym_traffic.h), drawn through the oracle: distributions of A.7."""
+    meta, _ = load_traj("traj_nsfnet320")
+    h = holder_for(meta)
+    o = OracleEnv(h)
+    o.seed(123)
+    reqs = []
+    o.reset()
+    last = 0.0
+    for _ in range(6000):
+        q = o.request()
+        reqs.append((q["arrival_time"] - last, q["holding_time"], q["source"], q["destination"], q["bit_rate"]))
+        last = float(q["arrival_time"])
+        rc, r = o.step(o.reject_action)
+    a = np.array(reqs, dtype=np.float64)
+    assert a[:, 0].mean() == pytest.approx(10800 / 300, rel=0.05)
+    assert a[:, 1].mean() == pytest.approx(10800, rel=0.05)
+    assert (a[:, 2] != a[:, 3]).all()
+    assert np.bincount(a[:, 2].astype(int), minlength=14).min() > 6000 / 14 * 0.7
+    assert np.bincount(a[:, 3].astype(int), minlength=14).min() > 6000 / 14 * 0.7
+    assert set(np.unique(a[:, 4])) == {10.0, 40.0, 100.0, 400.0}
+
+
+def test_det_log_accuracy():
+    """ongym_det_log (exactly rounded ops only) is within 2 ulp of libm over the range the stream uses."""
+    src = r'''
+    #include <stdio.h>
+    #include "%s/include/ongym_traffic.h"
+    int main(void){ double worst=0; for (int i=1;i<200000;i++){ double x=(double)i/200000.0; double a=ongym_det_log(x), b=log(x);
+      double e=fabs(a-b)/fmax(fabs(b),1e-300); if(e>worst) worst=e;} double x=ldexp(1.0,-53); printf("%%.3e %%.17g %%.17g\n", worst, ongym_det_log(x), log(x)); return 0; }
+    ''' % REPO
+    exe = os.path.join("/tmp", "ongym_det_log_test")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-x", "c", "-", "-o", exe, "-lm"], input=src.encode(), check=True)
+    worst, a, b = subprocess.run([exe], capture_output=True, check=True).stdout.split()
+    assert float(worst) < 5e-16 and float(a) == pytest.approx(float(b), rel=1e-15)
+
+
+# ---- multi-rank statistics reduction (the only collective of the N>1 path) ---------------------------------------------
+_WORKER = r'''
+import os, sys, json
+sys.path[:0] = [%r, %r]
+import numpy as np, torch, torch.distributed as dist
+from optical_networking_gym._dist import init_process_group, rank_seed, reduce_run_statistics
+from common import holder_for, load_traj
+from oracle_lib import OracleEnv
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+init_process_group("gloo")
+meta, _ = load_traj("traj_nsfnet320")
+h = holder_for(meta, batch=2)
+steps = 0; acc = 0
+for r in range(2):                       # each rank owns 2 replicas; the oracle stands in for the GPU engine on CPU
+    o = OracleEnv(h, replica=r); o.seed(rank_seed(7, rank)); o.reset()
+    rec = o.run_first_fit(150); steps += len(rec); acc += int(rec["accepted"].sum())
+delta, dt_max, k_ms = reduce_run_statistics(np.array([steps, acc], np.float64), 1.0 + rank, 10.0 * (rank + 1), dist, device="cpu")
+if rank == 0:
+    print(json.dumps(dict(delta=delta.tolist(), dt_max=dt_max, k_ms=k_ms)))
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_statistics_reduction_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % (os.path.join(REPO, "optical-networking-gym_amd"), os.path.join(REPO, "tests")))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    # single-process ground truth
+    from optical_networking_gym._dist import rank_seed
+    meta, _ = load_traj("traj_nsfnet320")
+    h = holder_for(meta, batch=2)
+    steps = acc = 0
+    for rank in range(2):
+        for r in range(2):
+            o = OracleEnv(h, replica=r); o.seed(rank_seed(7, rank)); o.reset()
+            rec = o.run_first_fit(150); steps += len(rec); acc += int(rec["accepted"].sum())
+    assert got["delta"] == [float(steps), float(acc)]
+    assert got["dt_max"] == 2.0 and got["k_ms"] == 20.0
