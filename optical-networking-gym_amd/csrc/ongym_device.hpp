@@ -65,6 +65,8 @@ struct Params {
     const double *link_w2;          // [E]    nspans * l_eff * l_eff / (L*1e3)
     const double *link_cl;          // [E]    pi^2 |beta2| * l_eff_a = pi^2 |beta2| / (2 alpha)
     const double *link_selfc;       // [E]    pi^2 |beta2| / (4 alpha)
+    const double *path_w1;          // [P]    sum_l w1_l over the path's links (uniform-alpha self term)
+    const double *self_asinh;       // [S+1]  asinh(pi^2 |b2| (slot_bw n)^2 / (4 alpha)) when alpha is uniform
     const double *bit_rates, *bit_rate_cum, *node_cum;
     int mod_se[kMaxMods];
     double mod_thr[kMaxMods];
@@ -77,20 +79,37 @@ struct Params {
     // request trace (req_mode == kReqTrace)
     const ongym_request *trace;
     long long trace_n;
+    unsigned long long *dbg;   // diagnostic build only (-DONGYM_STAMPS): per-phase cycle sums
 };
 
 // ---------------------------------------------------------------------------------------------------------------
 // LDS carve-up (dynamic shared memory), 8-byte aligned pieces first
 //   occ u64[E*W] | lw1 f64[E] | lw2 f64[E] | lcl f64[E] | lsc f64[E] | DevEnv | sa u32[C] | sb u32[C] | sr f32[C] |
-//   nreq i32[8] | list u16[C]
+//   lim f64[8] | nreq i32[8] | list u16[C]
 // ---------------------------------------------------------------------------------------------------------------
 __host__ __device__ inline size_t lds_bytes(int n_links, int row_words, int capacity) {
     size_t b = (size_t)n_links * row_words * 8 + (size_t)n_links * 32 + ((sizeof(DevEnv) + 7) & ~(size_t)7);
-    b += (size_t)capacity * 12 + 32 + (size_t)capacity * 2;
+    b += (size_t)capacity * 12 + 64 + 32 + (size_t)capacity * 2;
     return (b + 15) & ~(size_t)15;
 }
 
+#ifdef ONGYM_STAMPS
+#define ONGYM_NSTAMPS 10
+#define STAMP(c, idx)                                                         \
+    do {                                                                      \
+        unsigned long long _t = __builtin_amdgcn_s_memtime();                 \
+        (c).stamp_acc[idx] += _t - (c).stamp_last;                            \
+        (c).stamp_last = _t;                                                  \
+    } while (0)
+#else
+#define STAMP(c, idx) do { } while (0)
+#endif
+
 struct Ctx {
+#ifdef ONGYM_STAMPS
+    unsigned long long stamp_acc[ONGYM_NSTAMPS];
+    unsigned long long stamp_last;
+#endif
     const Params &P;
     int lane;
     int replica;
@@ -100,7 +119,11 @@ struct Ctx {
     uint32_t *sa, *sb;
     float *sr;
     int *nreq;
+    double *lim;       // LDS [8] linear-domain acceptance limits 10^(-(thr_m+margin)/10) of this replica
     uint16_t *list;
+    double node_cum_reg;   // node_cum[lane] (+inf beyond n_nodes) when n_nodes <= 64
+    double br_cum_reg;     // bit_rate_cum[lane] (+inf beyond n_bit_rates)
+    float br_reg;          // bit_rates[lane]
     int active;        // running services (wave-uniform, mirrored to e->st.active at store time)
     float min_rel;     // wave-uniform
     int lane_terms;    // per-lane interferer-link term counter (reduced once per launch)
@@ -121,7 +144,8 @@ __device__ __forceinline__ void ctx_bind(Ctx &c, unsigned char *smem) {
     c.sa = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(c.e) + ((sizeof(DevEnv) + 7) & ~(size_t)7));
     c.sb = c.sa + P.capacity;
     c.sr = reinterpret_cast<float *>(c.sb + P.capacity);
-    c.nreq = reinterpret_cast<int *>(c.sr + P.capacity);
+    c.lim = reinterpret_cast<double *>(c.sr + P.capacity);   // capacity is a multiple of 64 -> 8-byte aligned
+    c.nreq = reinterpret_cast<int *>(c.lim + 8);
     c.list = reinterpret_cast<uint16_t *>(c.nreq + 8);
 }
 
@@ -139,23 +163,56 @@ __device__ __forceinline__ double uniform_f64(double v) {
     u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
     return u.d;
 }
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {   // DPP lane permutation of a 64-bit value (two 32-bit movs)
+    union { double d; int i[2]; } a, b;
+    a.d = v;
+    b.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], CTRL, 0xF, 0xF, true);
+    b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], CTRL, 0xF, 0xF, true);
+    return b.d;
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    union { double d; int i[2]; } a;
+    a.d = v;
+    a.i[0] = __builtin_amdgcn_readlane(a.i[0], lane);
+    a.i[1] = __builtin_amdgcn_readlane(a.i[1], lane);
+    return a.d;
+}
+// Wave-wide fp64 sum, identical bits in every lane: symmetric DPP exchanges inside each row of 16 lanes
+// (quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror, row_mirror), then the 4 row sums through v_readlane.
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    return v;
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    v += dpp_f64<0x140>(v);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+// word of lane+1 within the first row of 16 lanes (0 past the row): DPP row_shl:1
+__device__ __forceinline__ uint64_t next_word(uint64_t x) {
+    union { uint64_t u; int i[2]; } a, b;
+    a.u = x;
+    b.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x101, 0xF, 0xF, true);
+    b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x101, 0xF, 0xF, true);
+    return b.u;
 }
 __device__ __forceinline__ uint64_t lanes_below(int lane) { return (1ull << lane) - 1ull; }
 
-// bit s of the result is set iff bits [s, s+m) of the multi-word bitmap are all set. Word w lives in lane w
-// (lanes >= number of words hold 0). Doubling: after a pass the run length covered is r.
-__device__ __forceinline__ uint64_t run_and(uint64_t x, int m) {
-    int r = 1;
+// Bit s of the result is set iff bits [s, s+m) of the multi-word bitmap are all set. Word w lives in lane w (< 16;
+// the other lanes hold 0). `x` enters as the run-AND for length r (r = 1: the bitmap itself) and leaves as the one for
+// m >= r: x_m = x_r & (x_r >> (m - r)) while m - r <= r, so consecutive modulations (non-decreasing slot counts) cost
+// one shift-AND each instead of a fresh log-step ladder.
+__device__ __forceinline__ uint64_t run_and(uint64_t x, int &r, int m) {
     while (r < m) {
         int s = min(r, m - r);
-        int q = s >> 6, t = s & 63;
-        uint64_t a = __shfl_down((unsigned long long)x, q);
-        uint64_t b = __shfl_down((unsigned long long)x, q + 1);
-        uint64_t y = t ? ((a >> t) | (b << (64 - t))) : a;
+        uint64_t y;
+        if (s < 64) {
+            y = (x >> s) | (next_word(x) << (64 - s));   // s >= 1
+        } else {
+            int q = s >> 6, t = s & 63;
+            uint64_t a = __shfl_down((unsigned long long)x, q);
+            uint64_t b = __shfl_down((unsigned long long)x, q + 1);
+            y = t ? ((a >> t) | (b << (64 - t))) : a;
+        }
         x &= y;
         r += s;
     }
@@ -250,29 +307,36 @@ __device__ __forceinline__ double asinh_diff(double U, double V) {
     return log((U + sqrt(fma(U, U, 1.0))) / (V + sqrt(fma(V, V, 1.0))));
 }
 
-// pass 2: GSNR/ASE/NLI (dB) of a candidate lightpath (path, slot s, n slots) against the compacted interferers.
+struct GnLin {          // noise-to-signal ratios in the linear domain (wave-uniform)
+    double ase, nli;    // acc_ase, acc_nli of core/osnr.pyx:133-135 summed over all spans
+};
+
+// pass 2: 1/SNR_ase and 1/SNR_nli of a candidate lightpath (path, slot s, n slots) against the compacted interferers.
 // Span-hoisted: every span of a link is identical (topology.pyx:288-299), so the per-span sums of core/osnr.pyx:50-135
 // collapse to per-link weights w1 = nspans*l_eff, w2 = nspans*l_eff*l_eff/(L*1e3) (quirk Q11).
 template <bool UNIFORM_ALPHA>
-__device__ __forceinline__ void gn_eval(Ctx &c, const PathRef &p, int L, int s, int n, double launch_power,
-                                        double out[3]) {
+__device__ __forceinline__ GnLin gn_eval(Ctx &c, const PathRef &p, int L, int s, int n, double launch_power) {
     const Params &P = c.P;
     const double bw = P.slot_bw * n;
     const int c2 = 2 * s + n;  // candidate centre in half-slots
     double part = 0.0;
-    // self-channel term asinh(pi^2 |b2| B^2 / (4 alpha)) per link (core/osnr.pyx:58-61), lane h owns link h
-    if (c.lane < p.hops) part = c.lw1[p.mylink] * asinh(c.lsc[p.mylink] * (bw * bw));
+    // self-channel term asinh(pi^2 |b2| B^2 / (4 alpha)) per link (core/osnr.pyx:58-61)
+    if (UNIFORM_ALPHA) {
+        if (c.lane == 0) part = P.path_w1[p.id] * P.self_asinh[n];
+    } else {
+        if (c.lane < p.hops) part = c.lw1[p.mylink] * asinh(c.lsc[p.mylink] * (bw * bw));
+    }
     int terms = 0;
     for (int j = c.lane; j < L; j += kWave) {
         int idx = c.list[j];
         uint32_t a = c.sa[idx], b = c.sb[idx];
         int pk = a & 0xFFFF, sk = a >> 16, nk = b & 0xFFFF, mk = (b >> 16) & 0xFF;
+        uint64_t m0 = P.path_mask[2 * pk] & p.m0, m1 = P.path_mask[2 * pk + 1] & p.m1;
         double bk = P.slot_bw * nk;
         int dfi = (2 * sk + nk) - c2;                      // centre distance in half-slots (exact)
         double adf = (0.5 * P.slot_bw) * (double)abs(dfi); // |fc_k - fc|
         double hi = adf + 0.5 * bk, lo = adf - 0.5 * bk;   // lo > 0: allocations never overlap
         double corr = P.mod_phi53[mk] * (bk / adf);
-        uint64_t m0 = P.path_mask[2 * pk] & p.m0, m1 = P.path_mask[2 * pk + 1] & p.m1;
         terms += __popcll((unsigned long long)m0) + __popcll((unsigned long long)m1);
         if (UNIFORM_ALPHA) {
             double ck = P.alpha0_cl * bk;
@@ -298,27 +362,36 @@ __device__ __forceinline__ void gn_eval(Ctx &c, const PathRef &p, int L, int s, 
     double ratio = launch_power / bw;
     double knli = (ratio * ratio * ratio) * (8.0 / (27.0 * pi * beta2)) * (gamma * gamma) * bw;
     double fc = P.f0 + (P.slot_bw * s) + (P.slot_bw * (n / 2.0));  // envs/qrmsa.pyx:901-905
-    double acc_nli = knli * total / launch_power;
-    double acc_ase = bw * fc * P.path_ase[p.id] / launch_power;
-    out[0] = 10.0 * log10(1.0 / (acc_ase + acc_nli));
-    out[1] = 10.0 * log10(1.0 / acc_ase);
-    out[2] = 10.0 * log10(1.0 / acc_nli);
+    GnLin g;
+    g.nli = knli * total / launch_power;
+    g.ase = bw * fc * P.path_ase[p.id] / launch_power;
+    return g;
+}
+
+__device__ __forceinline__ void gn_to_db(const GnLin &g, double out[3]) {   // core/osnr.pyx:138-140
+    out[0] = 10.0 * log10(1.0 / (g.ase + g.nli));
+    out[1] = 10.0 * log10(1.0 / g.ase);
+    out[2] = 10.0 * log10(1.0 / g.nli);
+}
+
+// GSNR >= minimum_osnr + margin ?  (heuristics.py:957-958, envs/qrmsa.pyx:911). The comparison is made in the linear
+// domain against lim = 10^(-(thr+margin)/10); inside a 1e-9 relative band around the limit it falls back to the
+// reference's own expression 10*log10(1/acc) >= thr + margin, so the decision is the dB-domain one everywhere.
+__device__ __forceinline__ int qot_ok(const Ctx &c, const GnLin &g, int m, double margin) {
+    double acc = g.ase + g.nli, lim = c.lim[m];
+    int ok;
+    if (acc <= lim * (1.0 - 1e-9)) ok = 1;
+    else if (acc >= lim * (1.0 + 1e-9)) ok = 0;
+    else ok = 10.0 * log10(1.0 / acc) >= c.P.mod_thr[m] + margin;
+    return uniform_i32(ok);
 }
 
 struct Choice {
-    int action, route, mod, slot, n;
+    int action, route, mod, slot, n, path;
     int flags;          // ONGYM_F_BLOCKED_*
     int hops, mylink;   // chosen path as lanes see it
-    double gn[3];
+    GnLin g;
 };
-
-// slots needed per modulation for the current request: get_number_slots (envs/qrmsa.pyx:1198-1205), lane m -> nreq[m]
-__device__ __forceinline__ void fill_number_slots(Ctx &c, float bit_rate) {
-    const Params &P = c.P;
-    if (c.lane < P.n_mods)
-        c.nreq[c.lane] = (int)ceil((double)bit_rate / ((double)P.mod_se[c.lane] * P.channel_width));
-    __syncthreads();
-}
 
 // ---- heuristic_shortest_available_path_first_fit_best_modulation (heuristics/heuristics.py:923-966) -----------
 template <bool UNIFORM_ALPHA>
@@ -327,28 +400,34 @@ __device__ __forceinline__ void policy_first_fit(Ctx &c, int src, int dst, doubl
     const Params &P = c.P;
     const int M = P.n_mods, S = P.n_slots, max_mod = M - 1;
     ch.action = P.k_paths * M * S; ch.route = -1; ch.mod = -1; ch.slot = -1; ch.n = 0; ch.hops = 0; ch.mylink = 0;
-    ch.gn[0] = ch.gn[1] = ch.gn[2] = 0.0;
+    ch.path = -1; ch.g.ase = ch.g.nli = 0.0;
     int bres = 0, bosnr = 0;
     for (int k = 0; k < P.k_paths; k++) {
         int path = P.pair_paths[(src * P.n_nodes + dst) * P.k_paths + k];
         if (path < 0) break;
         PathRef p = load_path(c, path);
         c.paths_tried++; c.path_hops += p.hops;
-        uint64_t free_ext = path_free_ext(c, p);
-        int L = -1;
+        const uint64_t free_ext = path_free_ext(c, p);
+        STAMP(c, 1);
+        uint64_t runs = free_ext;   // run-AND of length r, extended modulation by modulation
+        int r = 1, L = -1;
         for (int m = max_mod; m >= 0; m--) {
             int n = c.nreq[m];
             if (n <= 0) continue;
-            int first = first_set(run_and(free_ext, n + 1));
+            if (n + 1 < r) { runs = free_ext; r = 1; }   // slot counts normally grow as the modulation index falls
+            runs = run_and(runs, r, n + 1);
+            int first = first_set(runs);
+            STAMP(c, 2);
             if (first < 0) { bres = 1; continue; }
-            if (L < 0) L = gn_build_list(c, p.m0, p.m1);
-            double g[3];
-            gn_eval<UNIFORM_ALPHA>(c, p, L, first, n, launch_power, g);
-            int ok = uniform_i32(g[0] >= P.mod_thr[m] + margin);
+            if (L < 0) { L = gn_build_list(c, p.m0, p.m1); STAMP(c, 3); }
+            GnLin g = gn_eval<UNIFORM_ALPHA>(c, p, L, first, n, launch_power);
+            int ok = qot_ok(c, g, m, margin);
+            STAMP(c, 4);
             if (ok) {
                 ch.action = k * M * S + (max_mod - m) * S + first;   // get_action_index, heuristics.py:36-54
                 ch.route = k; ch.mod = m; ch.slot = first; ch.n = n; ch.hops = p.hops; ch.mylink = p.mylink;
-                ch.gn[0] = uniform_f64(g[0]); ch.gn[1] = uniform_f64(g[1]); ch.gn[2] = uniform_f64(g[2]);
+                ch.path = path;
+                ch.g.ase = uniform_f64(g.ase); ch.g.nli = uniform_f64(g.nli);
                 ch.flags = 0;
                 return;
             }
@@ -367,7 +446,7 @@ __device__ __forceinline__ int evaluate_action(Ctx &c, int src, int dst, double 
     const Params &P = c.P;
     const int M = P.n_mods, S = P.n_slots, max_mod = M - 1;
     ch.action = action; ch.route = -1; ch.mod = -1; ch.slot = -1; ch.n = 0; ch.flags = 0; ch.hops = 0; ch.mylink = 0;
-    ch.gn[0] = ch.gn[1] = ch.gn[2] = 0.0;
+    ch.path = -1; ch.g.ase = ch.g.nli = 0.0;
     if (action == P.k_paths * M * S) return 1;
     if (action < 0 || action > P.k_paths * M * S) return 2;
     int slot = action % S; int t = action / S;
@@ -377,18 +456,18 @@ __device__ __forceinline__ int evaluate_action(Ctx &c, int src, int dst, double 
     ch.route = route; ch.mod = m; ch.slot = slot;
     int path = P.pair_paths[(src * P.n_nodes + dst) * P.k_paths + route];
     int n = c.nreq[m];
-    ch.n = n;
+    ch.n = n; ch.path = path;
     if (path < 0 || n <= 0) return 2;
     PathRef p = load_path(c, path);
     ch.hops = p.hops; ch.mylink = p.mylink;
-    uint64_t ok_starts = run_and(path_free_ext(c, p), n + 1);     // is_path_free, envs/qrmsa.pyx:1248-1264
+    int rr = 1;
+    uint64_t ok_starts = run_and(path_free_ext(c, p), rr, n + 1);     // is_path_free, envs/qrmsa.pyx:1248-1264
     uint64_t w = __shfl((unsigned long long)ok_starts, slot >> 6);
     if (!((w >> (slot & 63)) & 1ull)) return 2;
     int L = gn_build_list(c, p.m0, p.m1);
-    double g[3];
-    gn_eval<UNIFORM_ALPHA>(c, p, L, slot, n, launch_power, g);
-    ch.gn[0] = uniform_f64(g[0]); ch.gn[1] = uniform_f64(g[1]); ch.gn[2] = uniform_f64(g[2]);
-    return uniform_i32(g[0] >= P.mod_thr[m] + margin) ? 0 : 3;
+    GnLin g = gn_eval<UNIFORM_ALPHA>(c, p, L, slot, n, launch_power);
+    ch.g.ase = uniform_f64(g.ase); ch.g.nli = uniform_f64(g.nli);
+    return qot_ok(c, g, m, margin) ? 0 : 3;
 }
 
 // ---- departures: release every running service with float32 key <= now (envs/qrmsa.pyx:1113-1122, 1332-1350) ---
@@ -427,33 +506,80 @@ __device__ __forceinline__ void release_due(Ctx &c, float now) {
     c.min_rel = mn;
 }
 
-// ---- _next_service, scalar half (envs/qrmsa.pyx:1067-1111): draw/replay the next request, advance the clock ----
-// Lane 0 only. Returns false if no request could be produced.
-__device__ __forceinline__ bool draw_next(const Params &P, DevEnv *e, int replica) {
-    if (e->have_request) return true;
+// ---- _next_service, request half (envs/qrmsa.pyx:1067-1111): draw/replay the next request, advance the clock ---
+// Wave-cooperative evaluation of ongym_draw_request (include/ongym_traffic.h) — the SAME operations, so the result is
+// bit-identical to the header's scalar definition: the two logarithms run in lanes 0 and 1, the three cumulative-table
+// searches are one __ballot each (first i with x < cum[i]  ==  number of cum[i] <= x among i < n-1).
+__device__ __forceinline__ int cum_search(const Ctx &c, const double *cum, double cum_reg, int n, double x) {
+    if (n <= kWave) return __popcll((unsigned long long)__ballot(c.lane < n - 1 && cum_reg <= x));
+    int cnt = 0;
+    for (int base = 0; base < n - 1; base += kWave) {
+        int i = base + c.lane;
+        cnt += __popcll((unsigned long long)__ballot(i < n - 1 && cum[i] <= x));
+    }
+    return cnt;
+}
+
+__device__ __forceinline__ void draw_next(Ctx &c) {
+    ONGYM_NO_CONTRACT
+    const Params &P = c.P;
+    DevEnv *e = c.e;
+    if (e->have_request) return;
     float at, ht, br; int src, dst;
     if (P.req_mode == kReqRng) {
-        ongym_traffic_params tp = {e->mean_iat, P.mean_holding, P.node_cum, P.n_nodes, P.bit_rate_mode, P.bit_rates,
-                                   P.bit_rate_cum, P.n_bit_rates, P.br_lo, P.br_hi};
-        ongym_drawn_request r = ongym_draw_request(e->rng_key, e->req_index, e->st.current_time, &tp);
-        at = r.arrival_time; ht = r.holding_time; br = r.bit_rate; src = r.source; dst = r.destination;
+        const uint64_t key = e->rng_key, ctr = e->req_index * ONGYM_DRAWS_PER_REQUEST;
+        const double u0 = ongym_uniform(key, ctr + 0), u1 = ongym_uniform(key, ctr + 1), u2 = ongym_uniform(key, ctr + 2),
+                     u3 = ongym_uniform(key, ctr + 3), u4 = ongym_uniform(key, ctr + 4);
+        double lg = ongym_det_log(1.0 - (c.lane == 1 ? u1 : u0));
+        double l0 = readlane_f64(lg, 0), l1 = readlane_f64(lg, 1);
+        double x0 = -l0 / (1.0 / e->mean_iat), x1 = -l1 / (1.0 / P.mean_holding);   // expovariate(1/mean)
+        at = (float)(e->st.current_time + x0);
+        ht = (float)x1;
+        const int n = P.n_nodes;
+        const bool small = n <= kWave;
+        double total = small ? __shfl(c.node_cum_reg, n - 1) : P.node_cum[n - 1];
+        src = cum_search(c, P.node_cum, c.node_cum_reg, n, u2 * total);
+        double hi_s = small ? __shfl(c.node_cum_reg, src) : P.node_cum[src];
+        double lo_s = src > 0 ? (small ? __shfl(c.node_cum_reg, src - 1) : P.node_cum[src - 1]) : 0.0;
+        double w_s = hi_s - lo_s;
+        double x = u3 * (total - w_s);
+        if (x >= lo_s) x += w_s;
+        dst = cum_search(c, P.node_cum, c.node_cum_reg, n, x);
+        if (dst == src) dst = (src + 1 < n) ? src + 1 : src - 1;
+        if (P.bit_rate_mode == 0) {
+            const int nb = P.n_bit_rates;
+            double tb = nb <= kWave ? __shfl(c.br_cum_reg, nb - 1) : P.bit_rate_cum[nb - 1];
+            int bi = cum_search(c, P.bit_rate_cum, c.br_cum_reg, nb, u4 * tb);
+            br = nb <= kWave ? __shfl(c.br_reg, bi) : (float)P.bit_rates[bi];
+        } else {
+            int span = P.br_hi - P.br_lo + 1;
+            int k = (int)(u4 * (double)span);
+            if (k >= span) k = span - 1;
+            br = (float)(P.br_lo + k);
+        }
     } else if (P.req_mode == kReqTrace && (long long)e->req_index < P.trace_n) {
-        const ongym_request q = P.trace[(long long)replica * P.trace_n + (long long)e->req_index];
+        const ongym_request q = P.trace[(long long)c.replica * P.trace_n + (long long)e->req_index];
         at = q.arrival_time; ht = q.holding_time; br = q.bit_rate; src = q.source; dst = q.destination;
     } else {
-        e->st.flags |= ONGYM_F_NO_REQUEST;
-        return false;
+        if (c.lane == 0) e->st.flags |= ONGYM_F_NO_REQUEST;
+        __syncthreads();
+        return;
     }
-    e->req_index++;
-    e->st.current_time = (double)at;
-    e->cur_at = at; e->cur_ht = ht; e->cur_br = br; e->cur_src = src; e->cur_dst = dst;
-    e->cur_id = (int32_t)e->st.episode_services_processed;
-    e->have_request = 1;
-    e->st.services_processed += 1;
-    e->st.episode_services_processed += 1;
-    e->st.bit_rate_requested += (double)br;
-    e->st.episode_bit_rate_requested += (double)br;
-    return true;
+    // slots needed per modulation: get_number_slots (envs/qrmsa.pyx:1198-1205), lane m -> nreq[m]
+    if (c.lane < P.n_mods)
+        c.nreq[c.lane] = (int)ceil((double)br / ((double)P.mod_se[c.lane] * P.channel_width));
+    if (c.lane == 0) {
+        e->req_index++;
+        e->st.current_time = (double)at;
+        e->cur_at = at; e->cur_ht = ht; e->cur_br = br; e->cur_src = src; e->cur_dst = dst;
+        e->cur_id = (int32_t)e->st.episode_services_processed;
+        e->have_request = 1;
+        e->st.services_processed += 1;
+        e->st.episode_services_processed += 1;
+        e->st.bit_rate_requested += (double)br;
+        e->st.episode_bit_rate_requested += (double)br;
+    }
+    __syncthreads();
 }
 
 // ---- reset (envs/qrmsa.pyx:427-504) ----------------------------------------------------------------------------
@@ -472,9 +598,9 @@ __device__ __forceinline__ void reset_env(Ctx &c) {
         s.bit_rate_requested = 0.0; s.bit_rate_provisioned = 0.0;   // :466-467
         s.episode_osnr_sum = 0.0;
         e->have_request = 0;
-        draw_next(P, e, c.replica);   // no departures possible: the network is empty
     }
     __syncthreads();
+    draw_next(c);   // no departures possible: the network is empty
 }
 
 __device__ __forceinline__ void snapshot_terminal(DevEnv *e) {   // info of the terminal step, envs/qrmsa.pyx:996-1060
@@ -512,7 +638,8 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
                 r.reward = -3.0 * (1.0 + failed);   // reward(), :1266-1271
                 r.retry = 1; r.flags |= ONGYM_F_BLOCKED_RESOURCES;
             } else {
-                r.flags |= ONGYM_F_QOT_ERROR; r.osnr = ch.gn[0]; r.route = (int16_t)ch.route; r.slot = (int16_t)ch.slot;
+                r.flags |= ONGYM_F_QOT_ERROR; r.osnr = 10.0 * log10(1.0 / (ch.g.ase + ch.g.nli));
+                r.route = (int16_t)ch.route; r.slot = (int16_t)ch.slot;
             }
             *rec = r;
         }
@@ -526,6 +653,7 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
         int end = ch.slot + ch.n; if (end < P.n_slots) end += 1;
         mark_links(c, ch.hops, ch.mylink, ch.slot, end, false);
     }
+    STAMP(c, 5);
     if (c.lane == 0) {
         ongym_stats &s = e->st;
         ongym_step_rec r;
@@ -534,9 +662,10 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
         r.osnr = 0.0; r.ase = 0.0; r.nli = 0.0; r.reward = 0.0; r.active = 0;
         double osnr = 0.0;
         if (outcome == 0) {
-            int path = P.pair_paths[(e->cur_src * P.n_nodes + e->cur_dst) * P.k_paths + ch.route];
+            double g[3];
+            gn_to_db(ch.g, g);              // the accepted service's OSNR/ASE/NLI in dB (once per step)
             rel = e->cur_at + e->cur_ht;   // float + float (:1329); compared as float32 (:1114-1115)
-            c.sa[c.active] = (uint32_t)path | ((uint32_t)ch.slot << 16);
+            c.sa[c.active] = (uint32_t)ch.path | ((uint32_t)ch.slot << 16);
             c.sb[c.active] = (uint32_t)ch.n | ((uint32_t)ch.mod << 16);
             c.sr[c.active] = rel;
             s.services_accepted += 1; s.episode_services_accepted += 1;
@@ -546,8 +675,8 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
             s.episode_modulation_hist[ch.mod] += 1;
             s.total_accepted += 1;
             r.accepted = 1; r.route = (int16_t)ch.route; r.modulation = (int16_t)ch.mod; r.slot = (int16_t)ch.slot;
-            r.nslots = (int16_t)ch.n; r.osnr = ch.gn[0]; r.ase = ch.gn[1]; r.nli = ch.gn[2];
-            osnr = ch.gn[0];
+            r.nslots = (int16_t)ch.n; r.osnr = g[0]; r.ase = g[1]; r.nli = g[2];
+            osnr = g[0];
             r.reward = 0.0;                       // reward() falls off the end when accepted (quirk Q1)
         } else {
             s.rejected += 1;                      // bl_reject (:865)
@@ -557,10 +686,9 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
         s.episode_osnr_sum += osnr;
         s.total_steps += 1;
         e->have_request = 0;
+        // the info dict is computed before the next request is drawn (:996-1050); the step terminates the episode
+        // iff that draw makes episode_services_processed reach episode_length (:1056)
         if (s.episode_services_processed + 1 == P.episode_length) snapshot_terminal(e);
-        draw_next(P, e, c.replica);
-        r.terminated = (uint8_t)(s.episode_services_processed == P.episode_length);
-        if (r.terminated) s.episodes_completed += 1;
         if (rec) *rec = r;
     }
     if (outcome == 0) {
@@ -569,11 +697,17 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
         c.min_rel = fminf(c.min_rel, rel);
     }
     __syncthreads();
+    draw_next(c);                                 // first half of _next_service (:1079-1111)
+    STAMP(c, 6);
     release_due(c, e->cur_at);                    // second half of _next_service (:1113-1122)
-    if (rec && c.lane == 0) rec->active = c.active;
-    c.active_sum += c.active;
+    STAMP(c, 7);
     int terminated = e->st.episode_services_processed == P.episode_length;
-    if (terminated && P.auto_reset) reset_env(c);
+    if (c.lane == 0) {
+        if (terminated) e->st.episodes_completed += 1;
+        if (rec) { rec->active = c.active; rec->terminated = (uint8_t)terminated; }
+    }
+    c.active_sum += c.active;
+    if (terminated && P.auto_reset) { __syncthreads(); reset_env(c); }
 }
 
 __device__ __forceinline__ void load_state(Ctx &c) {
@@ -588,9 +722,18 @@ __device__ __forceinline__ void load_state(Ctx &c) {
     int words = P.n_links * P.row_words;
     const uint64_t *g = P.occ + (size_t)c.replica * words;
     for (int i = c.lane; i < words; i += kWave) c.occ[i] = g[i];
+    // traffic tables, one entry per lane (ballot search in draw_next)
+    c.node_cum_reg = (c.lane < P.n_nodes && P.n_nodes <= kWave) ? P.node_cum[c.lane] : INFINITY;
+    c.br_cum_reg = (c.lane < P.n_bit_rates && P.n_bit_rates <= kWave) ? P.bit_rate_cum[c.lane] : INFINITY;
+    c.br_reg = (c.lane < P.n_bit_rates && P.n_bit_rates <= kWave) ? (float)P.bit_rates[c.lane] : 0.f;
     __syncthreads();
     c.active = c.e->st.active;
     c.min_rel = c.e->min_rel;
+    // per-replica acceptance limits in the linear domain (see qot_ok)
+    if (c.lane < P.n_mods) c.lim[c.lane] = pow(10.0, -(P.mod_thr[c.lane] + c.e->margin) / 10.0);
+    // slots needed by the current request (kept in LDS between requests, recomputed on load)
+    if (c.lane < P.n_mods)
+        c.nreq[c.lane] = (int)ceil((double)c.e->cur_br / ((double)P.mod_se[c.lane] * P.channel_width));
     size_t off = (size_t)c.replica * P.capacity;
     for (int i = c.lane; i < c.active; i += kWave) { c.sa[i] = P.svc_a[off + i]; c.sb[i] = P.svc_b[off + i]; c.sr[i] = P.svc_r[off + i]; }
     __syncthreads();

@@ -17,9 +17,10 @@ using namespace ongym;
 // kernels
 // ---------------------------------------------------------------------------------------------------------------
 template <bool UA>
-__global__ __launch_bounds__(64) void k_run(Params P, int mode, int nsteps, const int32_t *actions, int32_t *act_out,
+__global__ __launch_bounds__(64) void k_run(const Params *__restrict__ Pp, int mode, int nsteps, const int32_t *actions, int32_t *act_out,
                                             uint8_t *flag_out, ongym_step_rec *out) {
     extern __shared__ __align__(16) unsigned char smem[];
+    const Params &P = *Pp;
     Ctx c(P);
     c.lane = threadIdx.x;
     c.replica = blockIdx.x;
@@ -27,7 +28,12 @@ __global__ __launch_bounds__(64) void k_run(Params P, int mode, int nsteps, cons
     c.gn_evals = 0;
     c.paths_tried = 0; c.path_hops = 0; c.active_sum = 0;
     ctx_bind(c, smem);
+#ifdef ONGYM_STAMPS
+    for (int i = 0; i < ONGYM_NSTAMPS; i++) c.stamp_acc[i] = 0;
+    c.stamp_last = __builtin_amdgcn_s_memtime();
+#endif
     load_state(c);
+    STAMP(c, 8);
     for (int it = 0; it < nsteps; ++it) {
         DevEnv *e = c.e;
         ongym_step_rec *rec = out ? out + (size_t)it * P.batch + c.replica : nullptr;
@@ -44,7 +50,8 @@ __global__ __launch_bounds__(64) void k_run(Params P, int mode, int nsteps, cons
         int src = e->cur_src, dst = e->cur_dst;
         float br = e->cur_br;
         double lp = e->launch_power, mg = e->margin;
-        fill_number_slots(c, br);
+        (void)br;
+        STAMP(c, 0);
         Choice ch;
         int outcome;
         if (mode == kModeActionStep) {
@@ -60,11 +67,17 @@ __global__ __launch_bounds__(64) void k_run(Params P, int mode, int nsteps, cons
         apply_step(c, ch, outcome, rec);
     }
     if (mode != kModePolicyOnly) store_state(c);
+    STAMP(c, 9);
+#ifdef ONGYM_STAMPS
+    if (c.lane == 0 && P.dbg)
+        for (int i = 0; i < ONGYM_NSTAMPS; i++) atomicAdd(&P.dbg[i], c.stamp_acc[i]);
+#endif
 }
 
-__global__ __launch_bounds__(64) void k_reset(Params P, const uint8_t *mask) {
+__global__ __launch_bounds__(64) void k_reset(const Params *__restrict__ Pp, const uint8_t *mask) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (mask && !mask[blockIdx.x]) return;
+    const Params &P = *Pp;
     Ctx c(P);
     c.lane = threadIdx.x;
     c.replica = blockIdx.x;
@@ -93,9 +106,10 @@ __global__ void k_rewind(Params P) {   // new trace: cursor back to 0
 enum { kQAvailable = 0, kQGsnr = 1, kQGrid = 2, kQServices = 3, kQRequest = 4, kQCandidates = 5, kQPathFree = 6 };
 
 template <bool UA>
-__global__ __launch_bounds__(64) void k_query(Params P, int what, int replica, int path, int slot, int n,
+__global__ __launch_bounds__(64) void k_query(const Params *__restrict__ Pp, int what, int replica, int path, int slot, int n,
                                               int32_t *out_i, double *out_d) {
     extern __shared__ __align__(16) unsigned char smem[];
+    const Params &P = *Pp;
     Ctx c(P);
     c.lane = threadIdx.x;
     c.replica = replica;
@@ -114,8 +128,9 @@ __global__ __launch_bounds__(64) void k_query(Params P, int what, int replica, i
     } else if (what == kQGsnr) {        // calculate_osnr(env, candidate), core/osnr.pyx:21-142
         PathRef p = load_path(c, path);
         int L = gn_build_list(c, p.m0, p.m1);
+        GnLin lin = gn_eval<UA>(c, p, L, slot, n, c.e->launch_power);
         double g[3];
-        gn_eval<UA>(c, p, L, slot, n, c.e->launch_power, g);
+        gn_to_db(lin, g);
         if (c.lane == 0) { out_d[0] = g[0]; out_d[1] = g[1]; out_d[2] = g[2]; }
     } else if (what == kQGrid) {        // topology.graph["available_slots"]
         for (int i = c.lane; i < P.n_links * P.n_slots; i += kWave) {
@@ -139,14 +154,16 @@ __global__ __launch_bounds__(64) void k_query(Params P, int what, int replica, i
             if (sl < total && row[sl] != 0) x |= 1ull << j;
         }
         if (c.lane == (total >> 6)) x |= 1ull << (total & 63);
-        x = run_and(x, n + 1);
+        int rr = 1;
+        x = run_and(x, rr, n + 1);
         for (int j = 0; j < 64; j++) {
             int sl = c.lane * 64 + j;
             if (sl < total) out_i[1024 + sl] = (int32_t)((x >> j) & 1ull);
         }
     } else if (what == kQPathFree) {    // is_path_free, envs/qrmsa.pyx:1248-1264
         PathRef p = load_path(c, path);
-        uint64_t ok = run_and(path_free_ext(c, p), n + 1);
+        int rr = 1;
+        uint64_t ok = run_and(path_free_ext(c, p), rr, n + 1);
         uint64_t w = __shfl((unsigned long long)ok, slot >> 6);
         if (c.lane == 0) out_i[0] = (int32_t)((w >> (slot & 63)) & 1ull);
     } else if (what == kQRequest) {
@@ -164,6 +181,7 @@ __global__ __launch_bounds__(64) void k_query(Params P, int what, int replica, i
 struct ongym_env {
     ongym_config cfg{};
     Params P{};
+    Params *d_P = nullptr;          // device copy read by the kernels (scalar loads); refreshed by push_params
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -187,6 +205,11 @@ struct ongym_env {
     } while (0)
 
 static std::string g_create_error;
+
+static int push_params(ongym_env *env) {
+    HIP_TRY(env, hipMemcpyAsync(env->d_P, &env->P, sizeof(Params), hipMemcpyHostToDevice, env->stream));
+    return 0;
+}
 
 template <typename T>
 static int upload(ongym_env *env, const T *src, size_t n, const T **dst) {
@@ -274,13 +297,19 @@ static int build(ongym_env *env, const ongym_config *c) {
     P.uniform_alpha = uniform ? 1 : 0;
     P.alpha0_cl = cl[0];
     std::vector<uint64_t> mask((size_t)NP * 2, 0);
-    std::vector<double> path_ase(NP, 0.0);
+    std::vector<double> path_ase(NP, 0.0), path_w1(NP, 0.0);
     for (int p = 0; p < NP; p++)
         for (int h = 0; h < c->path_hops[p]; h++) {
             int l = c->path_links[p * H + h];
             mask[2 * p + (l >> 6)] |= 1ull << (l & 63);
             path_ase[p] += ase_link[l];
+            path_w1[p] += w1[l];
         }
+    std::vector<double> self_asinh((size_t)c->n_slots + 2, 0.0);   // uniform alpha only
+    for (int n = 0; n <= c->n_slots + 1; n++) {
+        double bwn = c->slot_bandwidth * n;
+        self_asinh[n] = std::asinh(selfc[0] * (bwn * bwn));
+    }
     static const double phi_mod[6] = {1.0, 1.0, 2.0 / 3.0, 17.0 / 25.0, 69.0 / 100.0, 13.0 / 21.0};
     for (int m = 0; m < M; m++) {
         P.mod_se[m] = c->mod_se[m];
@@ -293,6 +322,8 @@ static int build(ongym_env *env, const ongym_config *c) {
     if ((rc = upload(env, c->path_links, (size_t)NP * H, &P.path_links))) return rc;
     if ((rc = upload(env, mask.data(), mask.size(), &P.path_mask))) return rc;
     if ((rc = upload(env, path_ase.data(), path_ase.size(), &P.path_ase))) return rc;
+    if ((rc = upload(env, path_w1.data(), path_w1.size(), &P.path_w1))) return rc;
+    if ((rc = upload(env, self_asinh.data(), self_asinh.size(), &P.self_asinh))) return rc;
     if ((rc = upload(env, w1.data(), w1.size(), &P.link_w1))) return rc;
     if ((rc = upload(env, w2.data(), w2.size(), &P.link_w2))) return rc;
     if ((rc = upload(env, cl.data(), cl.size(), &P.link_cl))) return rc;
@@ -351,7 +382,11 @@ static int build(ongym_env *env, const ongym_config *c) {
     if ((rc = dev_alloc(env, B, &env->d_act_out, true))) return rc;
     if ((rc = dev_alloc(env, B, &env->d_flag_out, true))) return rc;
     if ((rc = dev_alloc(env, B, &env->d_mask, true))) return rc;
-    return 0;
+#ifdef ONGYM_STAMPS
+    if ((rc = dev_alloc(env, 16, &P.dbg, true))) return rc;
+#endif
+    if ((rc = dev_alloc(env, 1, &env->d_P, false))) return rc;
+    return push_params(env);
 }
 
 extern "C" {
@@ -437,6 +472,7 @@ int ongym_seed(ongym_env *env, uint64_t seed) {
     HIP_TRY(env, hipSetDevice(env->cfg.device));
     env->P.req_mode = kReqRng;
     env->has_source = true;
+    { int rc = push_params(env); if (rc) return rc; }
     int threads = 256, blocks = (env->P.batch + threads - 1) / threads;
     hipLaunchKernelGGL(k_seed, dim3(blocks), dim3(threads), 0, env->stream, env->P, seed);
     HIP_TRY(env, hipGetLastError());
@@ -466,6 +502,7 @@ int ongym_set_requests(ongym_env *env, const ongym_request *reqs, int64_t n_per_
     env->P.trace_n = n_per_replica;
     env->P.req_mode = kReqTrace;
     env->has_source = true;
+    { int rc = push_params(env); if (rc) return rc; }
     int threads = 256, blocks = (env->P.batch + threads - 1) / threads;
     hipLaunchKernelGGL(k_rewind, dim3(blocks), dim3(threads), 0, env->stream, env->P);
     HIP_TRY(env, hipGetLastError());
@@ -484,7 +521,7 @@ int ongym_reset(ongym_env *env, const uint8_t *mask) {
             dmask = env->d_mask;
         }
     }
-    hipLaunchKernelGGL(k_reset, dim3(env->P.batch), dim3(64), env->lds, env->stream, env->P, dmask);
+    hipLaunchKernelGGL(k_reset, dim3(env->P.batch), dim3(64), env->lds, env->stream, env->d_P, dmask);
     HIP_TRY(env, hipGetLastError());
     return ONGYM_OK;
 }
@@ -493,10 +530,10 @@ static int launch_run(ongym_env *env, int mode, int nsteps, const int32_t *d_act
                       uint8_t *d_flag_out, ongym_step_rec *d_out) {
     HIP_TRY(env, hipEventRecord(env->ev0, env->stream));
     if (env->P.uniform_alpha)
-        hipLaunchKernelGGL(k_run<true>, dim3(env->P.batch), dim3(64), env->lds, env->stream, env->P, mode, nsteps,
+        hipLaunchKernelGGL(k_run<true>, dim3(env->P.batch), dim3(64), env->lds, env->stream, env->d_P, mode, nsteps,
                            d_actions, d_act_out, d_flag_out, d_out);
     else
-        hipLaunchKernelGGL(k_run<false>, dim3(env->P.batch), dim3(64), env->lds, env->stream, env->P, mode, nsteps,
+        hipLaunchKernelGGL(k_run<false>, dim3(env->P.batch), dim3(64), env->lds, env->stream, env->d_P, mode, nsteps,
                            d_actions, d_act_out, d_flag_out, d_out);
     HIP_TRY(env, hipGetLastError());
     HIP_TRY(env, hipEventRecord(env->ev1, env->stream));
@@ -567,9 +604,9 @@ static int query(ongym_env *env, int what, int replica, int path, int slot, int 
     if (what == kQCandidates && (path <= 0 || path > 1023 || n <= 0 || n > 1023)) return fail_arg(env, "total_slots / nslots out of range");
     HIP_TRY(env, hipSetDevice(env->cfg.device));
     if (env->P.uniform_alpha)
-        hipLaunchKernelGGL(k_query<true>, dim3(1), dim3(64), env->lds, env->stream, env->P, what, replica, path, slot, n, env->d_scratch_i, env->d_scratch_d);
+        hipLaunchKernelGGL(k_query<true>, dim3(1), dim3(64), env->lds, env->stream, env->d_P, what, replica, path, slot, n, env->d_scratch_i, env->d_scratch_d);
     else
-        hipLaunchKernelGGL(k_query<false>, dim3(1), dim3(64), env->lds, env->stream, env->P, what, replica, path, slot, n, env->d_scratch_i, env->d_scratch_d);
+        hipLaunchKernelGGL(k_query<false>, dim3(1), dim3(64), env->lds, env->stream, env->d_P, what, replica, path, slot, n, env->d_scratch_i, env->d_scratch_d);
     HIP_TRY(env, hipGetLastError());
     return 0;
 }
@@ -659,5 +696,15 @@ int ongym_stats_get(ongym_env *env, ongym_stats *out) {
     if (flags & ONGYM_F_OVERFLOW) { env->err = "a replica overflowed its service table (raise capacity)"; return ONGYM_E_CAPACITY; }
     return ONGYM_OK;
 }
+
+#ifdef ONGYM_STAMPS
+// diagnostic build only: per-phase shader-cycle sums (not part of the ABI)
+int ongym_debug_stamps(ongym_env *env, unsigned long long *out16) {
+    HIP_TRY(env, hipStreamSynchronize(env->stream));
+    HIP_TRY(env, hipMemcpy(out16, env->P.dbg, 16 * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(env, hipMemset(env->P.dbg, 0, 16 * 8));
+    return 0;
+}
+#endif
 
 }  // extern "C"

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase shader-cycle shares of k_run from the -DONGYM_STAMPS build (never used for timing claims).
+
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DONGYM_STAMPS \
+        -o optical-networking-gym_amd/csrc/libongym_hip_stamps.so optical-networking-gym_amd/csrc/ongym_hip.hip
+    python tools/diag_stamps.py [--batch B] [--steps K]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(REPO, "optical-networking-gym_amd"), REPO]
+os.environ["ONGYM_HIP_LIB"] = os.path.join(REPO, "optical-networking-gym_amd", "csrc", "libongym_hip_stamps.so")
+
+import numpy as np  # noqa: E402
+import bench  # noqa: E402
+from optical_networking_gym.envs.batched import BatchedQRMSAEnv  # noqa: E402
+
+NAMES = ["0 request+nslots", "1 path load+AND", "2 run_and/first_set", "3 gn_build_list", "4 gn_eval", "5 mark_links",
+         "6 lane0 bookkeeping+draw", "7 release_due", "8 load_state", "9 store_state"]
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=65536)
+ap.add_argument("--steps", type=int, default=250)
+ap.add_argument("--workload", default="nsfnet320")
+args = ap.parse_args()
+wl = bench.WORKLOADS[args.workload]
+env = BatchedQRMSAEnv(tables=bench.build_tables(wl["topology"]), modulations=bench.jocn_modulations(),
+                      batch_size=args.batch, num_spectrum_resources=wl["S"], capacity=wl["capacity"],
+                      episode_length=1000, auto_reset=True, load=wl["load"], bit_rate_selection="discrete",
+                      bit_rates=wl["bit_rates"])
+env.seed(1); env.reset()
+env.step_policy(750, record=False)
+out = (C.c_ulonglong * 16)()
+env.lib.ongym_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
+env.lib.ongym_debug_stamps(env._h, out)
+env.step_policy(args.steps, record=False)
+env.sync()
+ms = env.last_kernel_ms()
+env.lib.ongym_debug_stamps(env._h, out)
+v = np.array(list(out)[:10], np.float64)
+tot = v.sum()
+print(f"kernel {ms:.2f} ms; {args.batch * args.steps / ms / 1e3:.3e} steps/s (stamped build)")
+for n, x in zip(NAMES, v):
+    print(f"  {n:28s} {100 * x / tot:5.1f} %   {x / (args.batch * args.steps):9.0f} cycles/step/wave")
+print(f"  total {tot / (args.batch * args.steps):.0f} cycles per env-step per wave")
