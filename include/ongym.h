@@ -151,6 +151,7 @@ typedef struct ongym_stats {
     /* totals over all completed steps since create (for throughput accounting and the RCCL stats reduction) */
     int64_t total_steps, total_accepted, total_gn_evals, total_interferer_terms;
     int64_t total_paths_tried, total_path_hops; /* candidate paths whose slot rows were read, and their hops */
+    int64_t total_gn_shortcuts;                 /* GN evaluations decided by the ASE-only bound (device only) */
     int64_t total_active_sum;                   /* sum over steps of the running-service count after the step */
     double current_time;
     int32_t active, flags;

@@ -36,6 +36,7 @@ enum ReqMode { kReqNone = 0, kReqRng = 1, kReqTrace = 2 };
 struct DevEnv {
     ongym_stats st;
     double launch_power, margin, mean_iat;   // per-replica parameters (sweeps as a batch dimension)
+    double lambd_iat;                        // 1.0 / mean_iat (expovariate's lambd)
     uint64_t rng_key;
     uint64_t req_index;                      // requests drawn so far (rng counter / trace cursor)
     float cur_at, cur_ht, cur_br;            // current_service (C floats in the reference, envs/qrmsa.pyx:35-37)
@@ -52,8 +53,11 @@ struct Params {
     int batch, capacity, episode_length, auto_reset;
     int bit_rate_mode, n_bit_rates, br_lo, br_hi;
     int uniform_alpha;
+    int ase_shortcut;   // 1: every interferer term of the NLI sum is provably >= 0 (checked on the host at create)
     int req_mode;
     double f0, slot_bw, channel_width, mean_holding;
+    double lambd_holding;           // 1.0 / mean_holding
+    const int32_t *nreq_tab;        // [n_bit_rates*8] slots needed per (discrete bit rate, modulation)
     double alpha0_cl;               // pi^2 |beta2| / (2 alpha) when alpha is uniform
     // constant tables
     const int32_t *pair_paths;      // [N*N*K]
@@ -128,6 +132,7 @@ struct Ctx {
     float min_rel;     // wave-uniform
     int lane_terms;    // per-lane interferer-link term counter (reduced once per launch)
     int gn_evals;      // wave-uniform
+    int gn_skips;      // wave-uniform: evaluations decided by the ASE-only bound
     int paths_tried, path_hops;   // wave-uniform statistics
     long long active_sum;
     __device__ Ctx(const Params &p) : P(p) {}
@@ -419,6 +424,22 @@ __device__ __forceinline__ void policy_first_fit(Ctx &c, int src, int dst, doubl
             int first = first_set(runs);
             STAMP(c, 2);
             if (first < 0) { bres = 1; continue; }
+            if (P.ase_shortcut) {
+                // No interferer term of the NLI sum is negative (checked at create), so
+                //   1/SNR >= 1/SNR_ase + 1/SNR_nli(self-channel term only):
+                // a candidate that fails on this O(1) bound fails the full evaluation too (same expressions as
+                // gn_eval, same 1e-9 guard band as qot_ok).
+                double bw = P.slot_bw * n;
+                double fc = P.f0 + (P.slot_bw * first) + (P.slot_bw * (n / 2.0));
+                double lb = bw * fc * P.path_ase[path] / launch_power;
+                if (UNIFORM_ALPHA) {
+                    const double pi = 3.14159265358979323846, beta2 = 21.3e-27, gamma = 1.3e-3;
+                    double ratio = launch_power / bw;
+                    double knli = (ratio * ratio * ratio) * (8.0 / (27.0 * pi * beta2)) * (gamma * gamma) * bw;
+                    lb += knli * (P.path_w1[path] * P.self_asinh[n]) / launch_power;
+                }
+                if (uniform_i32(lb >= c.lim[m] * (1.0 + 1e-9))) { bosnr = 1; bres = 0; c.gn_skips++; continue; }
+            }
             if (L < 0) { L = gn_build_list(c, p.m0, p.m1); STAMP(c, 3); }
             GnLin g = gn_eval<UNIFORM_ALPHA>(c, p, L, first, n, launch_power);
             int ok = qot_ok(c, g, m, margin);
@@ -525,14 +546,14 @@ __device__ __forceinline__ void draw_next(Ctx &c) {
     const Params &P = c.P;
     DevEnv *e = c.e;
     if (e->have_request) return;
-    float at, ht, br; int src, dst;
+    float at, ht, br; int src, dst, bi = -1;
     if (P.req_mode == kReqRng) {
         const uint64_t key = e->rng_key, ctr = e->req_index * ONGYM_DRAWS_PER_REQUEST;
         const double u0 = ongym_uniform(key, ctr + 0), u1 = ongym_uniform(key, ctr + 1), u2 = ongym_uniform(key, ctr + 2),
                      u3 = ongym_uniform(key, ctr + 3), u4 = ongym_uniform(key, ctr + 4);
         double lg = ongym_det_log(1.0 - (c.lane == 1 ? u1 : u0));
         double l0 = readlane_f64(lg, 0), l1 = readlane_f64(lg, 1);
-        double x0 = -l0 / (1.0 / e->mean_iat), x1 = -l1 / (1.0 / P.mean_holding);   // expovariate(1/mean)
+        double x0 = -l0 / e->lambd_iat, x1 = -l1 / P.lambd_holding;   // expovariate(lambd), lambd = 1.0/mean
         at = (float)(e->st.current_time + x0);
         ht = (float)x1;
         const int n = P.n_nodes;
@@ -549,7 +570,7 @@ __device__ __forceinline__ void draw_next(Ctx &c) {
         if (P.bit_rate_mode == 0) {
             const int nb = P.n_bit_rates;
             double tb = nb <= kWave ? __shfl(c.br_cum_reg, nb - 1) : P.bit_rate_cum[nb - 1];
-            int bi = cum_search(c, P.bit_rate_cum, c.br_cum_reg, nb, u4 * tb);
+            bi = cum_search(c, P.bit_rate_cum, c.br_cum_reg, nb, u4 * tb);
             br = nb <= kWave ? __shfl(c.br_reg, bi) : (float)P.bit_rates[bi];
         } else {
             int span = P.br_hi - P.br_lo + 1;
@@ -567,7 +588,8 @@ __device__ __forceinline__ void draw_next(Ctx &c) {
     }
     // slots needed per modulation: get_number_slots (envs/qrmsa.pyx:1198-1205), lane m -> nreq[m]
     if (c.lane < P.n_mods)
-        c.nreq[c.lane] = (int)ceil((double)br / ((double)P.mod_se[c.lane] * P.channel_width));
+        c.nreq[c.lane] = bi >= 0 ? P.nreq_tab[bi * kMaxMods + c.lane]
+                                 : (int)ceil((double)br / ((double)P.mod_se[c.lane] * P.channel_width));
     if (c.lane == 0) {
         e->req_index++;
         e->st.current_time = (double)at;
@@ -662,8 +684,8 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
         r.osnr = 0.0; r.ase = 0.0; r.nli = 0.0; r.reward = 0.0; r.active = 0;
         double osnr = 0.0;
         if (outcome == 0) {
-            double g[3];
-            gn_to_db(ch.g, g);              // the accepted service's OSNR/ASE/NLI in dB (once per step)
+            double g[3] = {10.0 * log10(1.0 / (ch.g.ase + ch.g.nli)), 0.0, 0.0};   // Service.OSNR (once per step)
+            if (rec) { g[1] = 10.0 * log10(1.0 / ch.g.ase); g[2] = 10.0 * log10(1.0 / ch.g.nli); }
             rel = e->cur_at + e->cur_ht;   // float + float (:1329); compared as float32 (:1114-1115)
             c.sa[c.active] = (uint32_t)ch.path | ((uint32_t)ch.slot << 16);
             c.sb[c.active] = (uint32_t)ch.n | ((uint32_t)ch.mod << 16);
@@ -748,6 +770,7 @@ __device__ __forceinline__ void store_state(Ctx &c) {
         c.e->st.active = c.active;
         c.e->min_rel = c.min_rel;
         c.e->st.total_gn_evals += c.gn_evals;
+        c.e->st.total_gn_shortcuts += c.gn_skips;
         c.e->st.total_interferer_terms += terms;
         c.e->st.total_paths_tried += c.paths_tried;
         c.e->st.total_path_hops += c.path_hops;

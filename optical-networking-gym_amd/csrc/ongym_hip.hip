@@ -17,7 +17,7 @@ using namespace ongym;
 // kernels
 // ---------------------------------------------------------------------------------------------------------------
 template <bool UA>
-__global__ __launch_bounds__(64) void k_run(const Params *__restrict__ Pp, int mode, int nsteps, const int32_t *actions, int32_t *act_out,
+__global__ __launch_bounds__(64, 4) void k_run(const Params *__restrict__ Pp, int mode, int nsteps, const int32_t *actions, int32_t *act_out,
                                             uint8_t *flag_out, ongym_step_rec *out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const Params &P = *Pp;
@@ -26,6 +26,7 @@ __global__ __launch_bounds__(64) void k_run(const Params *__restrict__ Pp, int m
     c.replica = blockIdx.x;
     c.lane_terms = 0;
     c.gn_evals = 0;
+    c.gn_skips = 0;
     c.paths_tried = 0; c.path_hops = 0; c.active_sum = 0;
     ctx_bind(c, smem);
 #ifdef ONGYM_STAMPS
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(64) void k_reset(const Params *__restrict__ Pp, con
     c.replica = blockIdx.x;
     c.lane_terms = 0;
     c.gn_evals = 0;
+    c.gn_skips = 0;
     c.paths_tried = 0; c.path_hops = 0; c.active_sum = 0;
     ctx_bind(c, smem);
     load_state(c);
@@ -115,6 +117,7 @@ __global__ __launch_bounds__(64) void k_query(const Params *__restrict__ Pp, int
     c.replica = replica;
     c.lane_terms = 0;
     c.gn_evals = 0;
+    c.gn_skips = 0;
     c.paths_tried = 0; c.path_hops = 0; c.active_sum = 0;
     ctx_bind(c, smem);
     load_state(c);
@@ -279,6 +282,7 @@ static int build(ongym_env *env, const ongym_config *c) {
     P.req_mode = kReqNone;
     P.f0 = c->frequency_start; P.slot_bw = c->slot_bandwidth; P.channel_width = c->channel_width;
     P.mean_holding = c->mean_holding_time;
+    P.lambd_holding = 1.0 / c->mean_holding_time;
 
     // derived GN tables in fp64 (core/osnr.pyx:22-24, 52-55, 58-61, 109-125)
     const double pi = 3.14159265358979323846, beta2 = 21.3e-27, h_planck = 6.626e-34;
@@ -316,7 +320,42 @@ static int build(ongym_env *env, const ongym_config *c) {
         P.mod_thr[m] = c->mod_min_osnr[m];
         P.mod_phi53[m] = phi_mod[c->mod_se[m] - 1] * (5.0 / 3.0);
     }
+    // slots needed per (discrete bit rate, modulation): get_number_slots, envs/qrmsa.pyx:1198-1205
+    std::vector<int32_t> nreq_tab((size_t)std::max(c->n_bit_rates, 1) * kMaxMods, 0);
+    if (c->bit_rate_mode == 0)
+        for (int b = 0; b < c->n_bit_rates; b++)
+            for (int m = 0; m < M; m++)
+                nreq_tab[(size_t)b * kMaxMods + m] =
+                    (int32_t)std::ceil((double)(float)c->bit_rates[b] / ((double)c->mod_se[m] * c->channel_width));
+    // ASE-only rejection is exact iff no interferer term asinh(u)-asinh(v) - Phi*(5/3)*(Bk/|df|)*(l_eff/L) of
+    // core/osnr.pyx:68-93 can be negative: scan the whole discrete domain (slot counts x centre distances in half
+    // slots x modulation formats x distinct link classes) once.
+    {
+        bool all_nonneg = true;
+        std::vector<std::pair<double, double>> classes;   // (cl, l_eff/(L*1e3))
+        for (int e = 0; e < E; e++) {
+            std::pair<double, double> k(cl[e], w2[e] / w1[e]);
+            bool seen = false;
+            for (auto &q : classes) if (q == k) seen = true;
+            if (!seen) classes.push_back(k);
+        }
+        const int S = c->n_slots;
+        for (auto &cls : classes)
+            for (int m = 0; m < M && all_nonneg; m++) {
+                const double K = P.mod_phi53[m] * cls.second;
+                for (int nk = 1; nk <= S && all_nonneg; nk++) {
+                    const double bk = c->slot_bandwidth * nk, ck = cls.first * bk;
+                    for (int dfi = nk + 1; dfi <= 2 * S; dfi++) {
+                        const double adf = 0.5 * c->slot_bandwidth * dfi;
+                        const double t = (std::asinh(ck * (adf + 0.5 * bk)) - std::asinh(ck * (adf - 0.5 * bk))) - K * (bk / adf);
+                        if (!(t > 0.0)) { all_nonneg = false; break; }
+                    }
+                }
+            }
+        P.ase_shortcut = all_nonneg ? 1 : 0;
+    }
     int rc;
+    if ((rc = upload(env, nreq_tab.data(), nreq_tab.size(), &P.nreq_tab))) return rc;
     if ((rc = upload(env, c->pair_paths, (size_t)N * N * K, &P.pair_paths))) return rc;
     if ((rc = upload(env, c->path_hops, (size_t)NP, &P.path_hops))) return rc;
     if ((rc = upload(env, c->path_links, (size_t)NP * H, &P.path_links))) return rc;
@@ -350,6 +389,7 @@ static int build(ongym_env *env, const ongym_config *c) {
         double load = c->replica_load ? c->replica_load[r] : c->load;
         if (!(load > 0) || !(d.launch_power > 0)) return fail_arg(env, "per-replica load / launch power must be positive");
         d.mean_iat = 1 / (load / c->mean_holding_time);   // set_load, envs/qrmsa.pyx:1124-1132
+        d.lambd_iat = 1.0 / d.mean_iat;
         d.min_rel = INFINITY;
     }
     HIP_TRY(env, hipMemcpy(P.env, host.data(), B * sizeof(DevEnv), hipMemcpyHostToDevice));

@@ -63,7 +63,7 @@ STATS_DTYPE = np.dtype([
     ("last_modulation_hist", "<i8", (8,)), ("last_mean_gsnr", "<f8"),
     ("total_steps", "<i8"), ("total_accepted", "<i8"), ("total_gn_evals", "<i8"),
     ("total_interferer_terms", "<i8"), ("total_paths_tried", "<i8"), ("total_path_hops", "<i8"),
-    ("total_active_sum", "<i8"), ("current_time", "<f8"), ("active", "<i4"), ("flags", "<i4")], align=True)
+    ("total_gn_shortcuts", "<i8"), ("total_active_sum", "<i8"), ("current_time", "<f8"), ("active", "<i4"), ("flags", "<i4")], align=True)
 
 
 class ConfigHolder:

@@ -531,7 +531,8 @@ void orc_stats(const orc_env *e, ongym_stats *s) {
     s->episode_osnr_sum = e->ep_osnr_sum; s->episodes_completed = e->episodes_completed;
     s->total_steps = e->total_steps; s->total_accepted = e->total_accepted; s->total_gn_evals = e->total_gn;
     s->total_interferer_terms = e->total_terms; s->total_paths_tried = e->total_paths;
-    s->total_path_hops = e->total_hops; s->total_active_sum = e->total_active_sum; s->current_time = e->current_time; s->active = e->n_running;
+    s->total_path_hops = e->total_hops; s->total_active_sum = e->total_active_sum;
+    s->total_gn_shortcuts = 0; s->current_time = e->current_time; s->active = e->n_running;
     s->flags = e->flags;
 }
 

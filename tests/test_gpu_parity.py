@@ -162,10 +162,13 @@ def test_random_traffic_vs_oracle(topo, S, load, steps):
         o = oracles[r].stats()
         for f in ("services_processed", "services_accepted", "episode_services_processed", "episode_services_accepted",
                   "bit_rate_requested", "bit_rate_provisioned", "episode_bit_rate_provisioned", "rejected",
-                  "episodes_completed", "total_steps", "total_accepted", "total_gn_evals", "total_interferer_terms", "total_paths_tried", "total_path_hops",
+                  "episodes_completed", "total_steps", "total_accepted", "total_paths_tried", "total_path_hops",
                   "total_active_sum",
                   "current_time", "active", "last_episode_accepted", "last_service_blocking_rate"):
             assert st[r][f] == o[f], (r, f, st[r][f], o[f])
+        # the device may settle an evaluation by the ASE-only bound instead of the full interferer sum
+        assert st[r]["total_gn_evals"] + st[r]["total_gn_shortcuts"] == o["total_gn_evals"]
+        assert st[r]["total_interferer_terms"] <= o["total_interferer_terms"]
         np.testing.assert_array_equal(st[r]["episode_modulation_hist"], o["episode_modulation_hist"])
         np.testing.assert_array_equal(env.grid(r), oracles[r].grid())
         # plugin-API queries on a loaded network
