@@ -71,6 +71,9 @@ struct Params {
     const double *link_selfc;       // [E]    pi^2 |beta2| / (4 alpha)
     const double *path_w1;          // [P]    sum_l w1_l over the path's links (uniform-alpha self term)
     const double *self_asinh;       // [S+1]  asinh(pi^2 |b2| (slot_bw n)^2 / (4 alpha)) when alpha is uniform
+    const double2 *pair_tab;        // [tab_nmax][2S+1] (asinh difference, Bk/|df|) by (interferer slots, centre distance in
+                                    //  half slots), uniform alpha only; NULL = always compute
+    int tab_nmax, tab_stride;
     const double *bit_rates, *bit_rate_cum, *node_cum;
     int mod_se[kMaxMods];
     double mod_thr[kMaxMods];
@@ -192,6 +195,13 @@ __device__ __forceinline__ double wave_sum(double v) {
     v += dpp_f64<0x140>(v);
     return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {   // lane must be wave-uniform
+    union { uint64_t u; int i[2]; } a;
+    a.u = v;
+    a.i[0] = __builtin_amdgcn_readlane(a.i[0], lane);
+    a.i[1] = __builtin_amdgcn_readlane(a.i[1], lane);
+    return a.u;
+}
 // word of lane+1 within the first row of 16 lanes (0 past the row): DPP row_shl:1
 __device__ __forceinline__ uint64_t next_word(uint64_t x) {
     union { uint64_t u; int i[2]; } a, b;
@@ -229,7 +239,7 @@ __device__ __forceinline__ int first_set(uint64_t x) {
     uint64_t bal = __ballot(x != 0);
     if (!bal) return -1;
     int fl = __ffsll((unsigned long long)bal) - 1;
-    uint64_t w = __shfl((unsigned long long)x, fl);
+    uint64_t w = readlane_u64(x, fl);
     return fl * 64 + (__ffsll((unsigned long long)w) - 1);
 }
 
@@ -266,7 +276,7 @@ __device__ __forceinline__ uint64_t path_free_ext(const Ctx &c, const PathRef &p
     const Params &P = c.P;
     uint64_t x = (c.lane < P.row_words) ? ~0ull : 0ull;
     for (int h = 0; h < p.hops; h++) {
-        int l = __shfl(p.mylink, h);
+        int l = __builtin_amdgcn_readlane(p.mylink, h);
         if (c.lane < P.row_words) x &= c.occ[l * P.row_words + c.lane];
     }
     if (c.lane == (P.n_slots >> 6)) x |= 1ull << (P.n_slots & 63);
@@ -341,11 +351,20 @@ __device__ __forceinline__ GnLin gn_eval(Ctx &c, const PathRef &p, int L, int s,
         int dfi = (2 * sk + nk) - c2;                      // centre distance in half-slots (exact)
         double adf = (0.5 * P.slot_bw) * (double)abs(dfi); // |fc_k - fc|
         double hi = adf + 0.5 * bk, lo = adf - 0.5 * bk;   // lo > 0: allocations never overlap
-        double corr = P.mod_phi53[mk] * (bk / adf);
+        double corr = 0.0;
+        if (!UNIFORM_ALPHA || nk > P.tab_nmax) corr = P.mod_phi53[mk] * (bk / adf);
         terms += __popcll((unsigned long long)m0) + __popcll((unsigned long long)m1);
         if (UNIFORM_ALPHA) {
-            double ck = P.alpha0_cl * bk;
-            double A = asinh_diff(ck * hi, ck * lo);
+            double A;
+            int adi = abs(dfi);
+            if (nk <= P.tab_nmax) {   // (asinh difference, Bk/|df|) depend on two small integers only: one 16-byte gather
+                double2 t = P.pair_tab[(nk - 1) * P.tab_stride + adi];
+                A = t.x;
+                corr = P.mod_phi53[mk] * t.y;
+            } else {
+                double ck = P.alpha0_cl * bk;
+                A = asinh_diff(ck * hi, ck * lo);
+            }
             double w1 = 0.0, w2 = 0.0;
             while (m0) { int l = __ffsll((unsigned long long)m0) - 1; m0 &= m0 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
             while (m1) { int l = 64 + __ffsll((unsigned long long)m1) - 1; m1 &= m1 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
@@ -483,7 +502,7 @@ __device__ __forceinline__ int evaluate_action(Ctx &c, int src, int dst, double 
     ch.hops = p.hops; ch.mylink = p.mylink;
     int rr = 1;
     uint64_t ok_starts = run_and(path_free_ext(c, p), rr, n + 1);     // is_path_free, envs/qrmsa.pyx:1248-1264
-    uint64_t w = __shfl((unsigned long long)ok_starts, slot >> 6);
+    uint64_t w = readlane_u64(ok_starts, uniform_i32(slot >> 6));
     if (!((w >> (slot & 63)) & 1ull)) return 2;
     int L = gn_build_list(c, p.m0, p.m1);
     GnLin g = gn_eval<UNIFORM_ALPHA>(c, p, L, slot, n, launch_power);

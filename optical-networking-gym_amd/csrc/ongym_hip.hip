@@ -355,6 +355,39 @@ static int build(ongym_env *env, const ongym_config *c) {
         P.ase_shortcut = all_nonneg ? 1 : 0;
     }
     int rc;
+    // (asinh difference, Bk/|df|) table of core/osnr.pyx:68-93 for uniform attenuation. Both factors depend only on the
+    // interferer's slot count nk and the centre distance in half slots: precompute them in fp64 with the device's own
+    // expressions. nk range: the largest slot count the configured traffic can produce (anything larger, e.g. from a
+    // replayed trace, is computed on the fly by the kernel).
+    P.pair_tab = nullptr; P.tab_nmax = 0; P.tab_stride = 2 * c->n_slots + 1;
+    if (uniform) {
+        double max_rate = 0.0;
+        if (c->bit_rate_mode == 0) for (int b = 0; b < c->n_bit_rates; b++) max_rate = std::max(max_rate, c->bit_rates[b]);
+        else max_rate = (double)c->bit_rate_hi;
+        int min_se = 6;
+        for (int m = 0; m < M; m++) min_se = std::min(min_se, (int)c->mod_se[m]);
+        int nmax = (int)std::ceil(max_rate / ((double)min_se * c->channel_width));
+        nmax = std::max(1, std::min(nmax, c->n_slots));
+        size_t entries = (size_t)nmax * P.tab_stride;
+        if (entries * sizeof(double2) <= (size_t)16 << 20) {
+            std::vector<double2> tab(entries);
+            for (int nk = 1; nk <= nmax; nk++) {
+                const double bk = c->slot_bandwidth * nk, ck = cl[0] * bk;
+                for (int d = 0; d < P.tab_stride; d++) {
+                    double2 v; v.x = 0.0; v.y = 0.0;
+                    if (d > nk) {   // allocations never overlap: |df| > Bk/2
+                        const double adf = (0.5 * c->slot_bandwidth) * (double)d;
+                        const double U = ck * (adf + 0.5 * bk), V = ck * (adf - 0.5 * bk);
+                        v.x = std::log((U + std::sqrt(std::fma(U, U, 1.0))) / (V + std::sqrt(std::fma(V, V, 1.0))));
+                        v.y = bk / adf;
+                    }
+                    tab[(size_t)(nk - 1) * P.tab_stride + d] = v;
+                }
+            }
+            if ((rc = upload(env, tab.data(), tab.size(), &P.pair_tab))) return rc;
+            P.tab_nmax = nmax;
+        }
+    }
     if ((rc = upload(env, nreq_tab.data(), nreq_tab.size(), &P.nreq_tab))) return rc;
     if ((rc = upload(env, c->pair_paths, (size_t)N * N * K, &P.pair_paths))) return rc;
     if ((rc = upload(env, c->path_hops, (size_t)NP, &P.path_hops))) return rc;
