@@ -5,14 +5,14 @@
  * reference stream to reproduce bit-for-bit; what defines parity is the DISTRIBUTION and the DRAW ORDER of
  * QRMSAEnv._next_service / _get_node_pair (qrmsa.pyx:1079-1089, 1134-1148):
  *     1. at  = float32(current_time + expovariate(1/mean_inter_arrival))      mean_iat = 1/(load/holding) (:1130)
- *     2. ht  = float32(expovariate(1/mean_holding))
+ *     2. ht  = float32(expovariate(1/mean_holding))                            (both sampled in float32 here)
  *     3. src ~ node_request_probabilities
  *     4. dst ~ the same weights with src zeroed and renormalised
  *     5. bit_rate ~ choices(bit_rates, probs)  |  randint(lo, hi)
  * This header fixes one counter-based generator with exactly that order (5 draws per request) so that the HIP kernels
  * and any host-side checker produce the same requests from (seed, replica, request index).  Every operation below is an
- * IEEE-754 correctly rounded one (+, *, /, fma) or an integer one, so host and device agree bit for bit; the natural
- * logarithm is therefore spelled out instead of calling libm / ocml.
+ * IEEE-754 correctly rounded one (+, *, fma, conversions) or an integer one, so host and device agree bit for bit; the
+ * natural logarithm is therefore spelled out instead of calling libm / ocml.
  *
  * Usable from C (gcc, compile with -ffp-contract=off), C++ and HIP device code.
  */
@@ -53,42 +53,39 @@ ONGYM_HD double ongym_uniform(uint64_t key, uint64_t counter) {
     return (double)(x >> 11) * (1.0 / 9007199254740992.0);
 }
 
-/* natural log for normal positive x, ~1 ulp, built from exactly rounded operations only */
-ONGYM_HD double ongym_det_log(double x) {
+/*
+ * float32 natural logarithm of a double x in (0, 1] (x = 1 - u is exact in double). Built from exactly rounded
+ * float operations only (conversion, fmaf, multiply) so host and device agree bit for bit; no division.
+ * log(m), m in (sqrt(1/2), sqrt(2)], is a degree-9 polynomial in f = m - 1 (max abs error 3.4e-8).
+ */
+ONGYM_HD float ongym_logf_det(double x) {
     ONGYM_NO_CONTRACT
     union { double d; uint64_t u; } v;
     v.d = x;
     int e = (int)((v.u >> 52) & 0x7FF) - 1023;
     v.u = (v.u & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull; /* m in [1,2) */
-    double m = v.d;
-    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }        /* m in (sqrt(1/2), sqrt(2)] */
-    double f = m - 1.0;
-    double s = f / (2.0 + f);
-    double z = s * s;
-    /* log(m) = 2s * (1 + z/3 + z^2/5 + ... ), |z| <= 0.0295 */
-    double p = 1.0 / 27.0;
-    p = fma(p, z, 1.0 / 25.0);
-    p = fma(p, z, 1.0 / 23.0);
-    p = fma(p, z, 1.0 / 21.0);
-    p = fma(p, z, 1.0 / 19.0);
-    p = fma(p, z, 1.0 / 17.0);
-    p = fma(p, z, 1.0 / 15.0);
-    p = fma(p, z, 1.0 / 13.0);
-    p = fma(p, z, 1.0 / 11.0);
-    p = fma(p, z, 1.0 / 9.0);
-    p = fma(p, z, 1.0 / 7.0);
-    p = fma(p, z, 1.0 / 5.0);
-    p = fma(p, z, 1.0 / 3.0);
-    double lm = fma(p * z, 2.0 * s, 2.0 * s);
-    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-    double de = (double)e;
-    return fma(de, ln2_hi, fma(de, ln2_lo, lm));
+    float m = (float)v.d;                                         /* may round up to 2.0f: handled by the halving */
+    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+    float f = m - 1.0f;
+    float p = -0.07638592272996902f;
+    p = fmaf(p, f, 0.129141703248024f);
+    p = fmaf(p, f, -0.13240842521190643f);
+    p = fmaf(p, f, 0.14180079102516174f);
+    p = fmaf(p, f, -0.16609126329421997f);
+    p = fmaf(p, f, 0.2000207155942917f);
+    p = fmaf(p, f, -0.25001585483551025f);
+    p = fmaf(p, f, 0.33333325386047363f);
+    p = fmaf(p, f, -0.49999988079071045f);
+    p = fmaf(p, f, 1.0f);
+    return fmaf((float)e, 0.693147182464599609375f, p * f);
 }
 
-/* CPython: random.expovariate(lambd) = -log(1.0 - random()) / lambd */
-ONGYM_HD double ongym_expovariate(double u, double lambd) {
+/* random.expovariate(1/mean) = -log(1 - random()) / lambd, evaluated in float32 as -logf(1-u) * mean: the request
+ * clocks are C floats in the reference anyway (envs/qrmsa.pyx:1068-1075), the sampler's relative error is ~1e-7 */
+ONGYM_HD float ongym_expovariate_f(double u, float mean) {
     ONGYM_NO_CONTRACT
-    return -ongym_det_log(1.0 - u) / lambd; }
+    return -ongym_logf_det(1.0 - u) * mean;
+}
 
 /* first index i with x < cum[i] (CPython choices: bisect(cum_weights, u*total, 0, n-1)); cum[n-1] is the total */
 ONGYM_HD int ongym_bisect(const double *cum, int n, double x) {
@@ -128,8 +125,8 @@ ONGYM_HD ongym_drawn_request ongym_draw_request(uint64_t key, uint64_t index, do
     uint64_t c = index * ONGYM_DRAWS_PER_REQUEST;
     double u0 = ongym_uniform(key, c + 0), u1 = ongym_uniform(key, c + 1), u2 = ongym_uniform(key, c + 2),
            u3 = ongym_uniform(key, c + 3), u4 = ongym_uniform(key, c + 4);
-    r.arrival_time = (float)(current_time + ongym_expovariate(u0, 1.0 / tp->mean_inter_arrival));
-    r.holding_time = (float)ongym_expovariate(u1, 1.0 / tp->mean_holding);
+    r.arrival_time = (float)current_time + ongym_expovariate_f(u0, (float)tp->mean_inter_arrival);
+    r.holding_time = ongym_expovariate_f(u1, (float)tp->mean_holding);
     int n = tp->n_nodes;
     double total = tp->node_cum[n - 1];
     int src = ongym_bisect(tp->node_cum, n, u2 * total);

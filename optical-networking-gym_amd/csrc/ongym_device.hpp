@@ -36,7 +36,7 @@ enum ReqMode { kReqNone = 0, kReqRng = 1, kReqTrace = 2 };
 struct DevEnv {
     ongym_stats st;
     double launch_power, margin, mean_iat;   // per-replica parameters (sweeps as a batch dimension)
-    double lambd_iat;                        // 1.0 / mean_iat (expovariate's lambd)
+    float mean_iat_f, pad1;                  // (float)mean_iat: the sampler works in float32
     uint64_t rng_key;
     uint64_t req_index;                      // requests drawn so far (rng counter / trace cursor)
     float cur_at, cur_ht, cur_br;            // current_service (C floats in the reference, envs/qrmsa.pyx:35-37)
@@ -56,7 +56,7 @@ struct Params {
     int ase_shortcut;   // 1: every interferer term of the NLI sum is provably >= 0 (checked on the host at create)
     int req_mode;
     double f0, slot_bw, channel_width, mean_holding;
-    double lambd_holding;           // 1.0 / mean_holding
+    float mean_holding_f, pad_f;    // (float)mean_holding
     const int32_t *nreq_tab;        // [n_bit_rates*8] slots needed per (discrete bit rate, modulation)
     double alpha0_cl;               // pi^2 |beta2| / (2 alpha) when alpha is uniform
     // constant tables
@@ -131,6 +131,10 @@ struct Ctx {
     double node_cum_reg;   // node_cum[lane] (+inf beyond n_nodes) when n_nodes <= 64
     double br_cum_reg;     // bit_rate_cum[lane] (+inf beyond n_bit_rates)
     float br_reg;          // bit_rates[lane]
+    // first candidate path of the CURRENT request, loaded right after the request was drawn so that the table
+    // round trips overlap the departures scan (id < 0: no such path)
+    int pre_id, pre_hops, pre_mylink;
+    uint64_t pre_m0, pre_m1;
     int active;        // running services (wave-uniform, mirrored to e->st.active at store time)
     float min_rel;     // wave-uniform
     int lane_terms;    // per-lane interferer-link term counter (reduced once per launch)
@@ -257,6 +261,18 @@ struct PathRef {
     int mylink;          // link index of hop `lane` (undefined for lane >= hops)
     uint64_t m0, m1;     // link mask
 };
+
+__device__ __forceinline__ void prefetch_first_path(Ctx &c, int src, int dst) {
+    const Params &P = c.P;
+    int path = P.pair_paths[(src * P.n_nodes + dst) * P.k_paths];
+    c.pre_id = path;
+    if (path >= 0) {
+        c.pre_hops = P.path_hops[path];
+        c.pre_mylink = (c.lane < c.pre_hops) ? P.path_links[path * P.max_hops + c.lane] : 0;
+        c.pre_m0 = P.path_mask[2 * path];
+        c.pre_m1 = P.path_mask[2 * path + 1];
+    }
+}
 
 __device__ __forceinline__ PathRef load_path(const Ctx &c, int path) {
     const Params &P = c.P;
@@ -427,9 +443,11 @@ __device__ __forceinline__ void policy_first_fit(Ctx &c, int src, int dst, doubl
     ch.path = -1; ch.g.ase = ch.g.nli = 0.0;
     int bres = 0, bosnr = 0;
     for (int k = 0; k < P.k_paths; k++) {
-        int path = P.pair_paths[(src * P.n_nodes + dst) * P.k_paths + k];
+        int path = k == 0 ? c.pre_id : P.pair_paths[(src * P.n_nodes + dst) * P.k_paths + k];
         if (path < 0) break;
-        PathRef p = load_path(c, path);
+        PathRef p;
+        if (k == 0) { p.id = path; p.hops = c.pre_hops; p.mylink = c.pre_mylink; p.m0 = c.pre_m0; p.m1 = c.pre_m1; }
+        else p = load_path(c, path);
         c.paths_tried++; c.path_hops += p.hops;
         const uint64_t free_ext = path_free_ext(c, p);
         STAMP(c, 1);
@@ -567,14 +585,16 @@ __device__ __forceinline__ void draw_next(Ctx &c) {
     if (e->have_request) return;
     float at, ht, br; int src, dst, bi = -1;
     if (P.req_mode == kReqRng) {
+        // the five uniforms of this request in lanes 0..4, the two logarithms in lanes 0 and 1
         const uint64_t key = e->rng_key, ctr = e->req_index * ONGYM_DRAWS_PER_REQUEST;
-        const double u0 = ongym_uniform(key, ctr + 0), u1 = ongym_uniform(key, ctr + 1), u2 = ongym_uniform(key, ctr + 2),
-                     u3 = ongym_uniform(key, ctr + 3), u4 = ongym_uniform(key, ctr + 4);
-        double lg = ongym_det_log(1.0 - (c.lane == 1 ? u1 : u0));
-        double l0 = readlane_f64(lg, 0), l1 = readlane_f64(lg, 1);
-        double x0 = -l0 / e->lambd_iat, x1 = -l1 / P.lambd_holding;   // expovariate(lambd), lambd = 1.0/mean
-        at = (float)(e->st.current_time + x0);
-        ht = (float)x1;
+        const double ul = ongym_uniform(key, ctr + (uint64_t)min(c.lane, ONGYM_DRAWS_PER_REQUEST - 1));
+        const double u0 = readlane_f64(ul, 0), u1 = readlane_f64(ul, 1), u2 = readlane_f64(ul, 2),
+                     u3 = readlane_f64(ul, 3), u4 = readlane_f64(ul, 4);
+        float lg = ongym_logf_det(1.0 - (c.lane == 1 ? u1 : u0));
+        float l0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lg), 0));
+        float l1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lg), 1));
+        at = (float)e->st.current_time + (-l0 * e->mean_iat_f);     // ongym_expovariate_f
+        ht = -l1 * P.mean_holding_f;
         const int n = P.n_nodes;
         const bool small = n <= kWave;
         double total = small ? __shfl(c.node_cum_reg, n - 1) : P.node_cum[n - 1];
@@ -606,6 +626,7 @@ __device__ __forceinline__ void draw_next(Ctx &c) {
         return;
     }
     // slots needed per modulation: get_number_slots (envs/qrmsa.pyx:1198-1205), lane m -> nreq[m]
+    prefetch_first_path(c, src, dst);
     if (c.lane < P.n_mods)
         c.nreq[c.lane] = bi >= 0 ? P.nreq_tab[bi * kMaxMods + c.lane]
                                  : (int)ceil((double)br / ((double)P.mod_se[c.lane] * P.channel_width));
@@ -770,6 +791,8 @@ __device__ __forceinline__ void load_state(Ctx &c) {
     __syncthreads();
     c.active = c.e->st.active;
     c.min_rel = c.e->min_rel;
+    c.pre_id = -1;
+    if (c.e->have_request) prefetch_first_path(c, c.e->cur_src, c.e->cur_dst);
     // per-replica acceptance limits in the linear domain (see qot_ok)
     if (c.lane < P.n_mods) c.lim[c.lane] = pow(10.0, -(P.mod_thr[c.lane] + c.e->margin) / 10.0);
     // slots needed by the current request (kept in LDS between requests, recomputed on load)

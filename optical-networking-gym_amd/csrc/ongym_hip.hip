@@ -282,7 +282,7 @@ static int build(ongym_env *env, const ongym_config *c) {
     P.req_mode = kReqNone;
     P.f0 = c->frequency_start; P.slot_bw = c->slot_bandwidth; P.channel_width = c->channel_width;
     P.mean_holding = c->mean_holding_time;
-    P.lambd_holding = 1.0 / c->mean_holding_time;
+    P.mean_holding_f = (float)c->mean_holding_time;
 
     // derived GN tables in fp64 (core/osnr.pyx:22-24, 52-55, 58-61, 109-125)
     const double pi = 3.14159265358979323846, beta2 = 21.3e-27, h_planck = 6.626e-34;
@@ -422,7 +422,7 @@ static int build(ongym_env *env, const ongym_config *c) {
         double load = c->replica_load ? c->replica_load[r] : c->load;
         if (!(load > 0) || !(d.launch_power > 0)) return fail_arg(env, "per-replica load / launch power must be positive");
         d.mean_iat = 1 / (load / c->mean_holding_time);   // set_load, envs/qrmsa.pyx:1124-1132
-        d.lambd_iat = 1.0 / d.mean_iat;
+        d.mean_iat_f = (float)d.mean_iat;
         d.min_rel = INFINITY;
     }
     HIP_TRY(env, hipMemcpy(P.env, host.data(), B * sizeof(DevEnv), hipMemcpyHostToDevice));

@@ -141,17 +141,17 @@ def test_device_stream_definition_statistics():
 
 
 def test_det_log_accuracy():
-    """ongym_det_log (exactly rounded ops only) is within 2 ulp of libm over the range the stream uses."""
+    """ongym_logf_det (exactly rounded float ops only): abs error < 1.5e-7 (+ relative 1e-7 of e*ln2) vs libm."""
     src = r'''
     #include <stdio.h>
     #include "%s/include/ongym_traffic.h"
-    int main(void){ double worst=0; for (int i=1;i<200000;i++){ double x=(double)i/200000.0; double a=ongym_det_log(x), b=log(x);
-      double e=fabs(a-b)/fmax(fabs(b),1e-300); if(e>worst) worst=e;} double x=ldexp(1.0,-53); printf("%%.3e %%.17g %%.17g\n", worst, ongym_det_log(x), log(x)); return 0; }
+    int main(void){ double worst=0; for (int i=1;i<=400000;i++){ double x=(double)i/400000.0; double a=ongym_logf_det(x), b=log(x);
+      double e=fabs(a-b)/fmax(fabs(b),1.0); if(e>worst) worst=e;} double x=ldexp(1.0,-53); printf("%%.3e %%.9g %%.9g\n", worst, (double)ongym_logf_det(x), log(x)); return 0; }
     ''' % REPO
     exe = os.path.join("/tmp", "ongym_det_log_test")
     subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-x", "c", "-", "-o", exe, "-lm"], input=src.encode(), check=True)
     worst, a, b = subprocess.run([exe], capture_output=True, check=True).stdout.split()
-    assert float(worst) < 5e-16 and float(a) == pytest.approx(float(b), rel=1e-15)
+    assert float(worst) < 1.5e-7 and float(a) == pytest.approx(float(b), rel=2e-7)
 
 
 # ---- multi-rank statistics reduction (the only collective of the N>1 path) ---------------------------------------------
