@@ -53,6 +53,7 @@ struct Params {
     int batch, capacity, episode_length, auto_reset;
     int bit_rate_mode, n_bit_rates, br_lo, br_hi;
     int uniform_alpha;
+    int rec32;          // record codec R32 in use (n_links <= 32, n_paths <= 512)
     int ase_shortcut;   // 1: every interferer term of the NLI sum is provably >= 0 (checked on the host at create)
     int req_mode;
     double f0, slot_bw, channel_width, mean_holding;
@@ -255,6 +256,21 @@ __device__ __forceinline__ uint64_t word_range(int w, int lo, int hi) {
     return m << a;
 }
 
+// ---- running-service record codec -------------------------------------------------------------------------------------
+// generic : a = path_id | slot<<16            b = nslots | modulation<<16          (link mask gathered from path_mask)
+// R32     : a = 32-bit link mask of the path   b = slot | nslots<<10 | modulation<<20 | path_id<<23
+//           (n_links <= 32, n_paths <= 512, n_slots <= 1023: NSFNET, COST239, rings) — the GN scans and the departures
+//           then need no table lookup per record at all.
+template <bool R32> __device__ __forceinline__ void rec_pack(int path, uint64_t mask0, int slot, int n, int mod,
+                                                             uint32_t &a, uint32_t &b) {
+    if (R32) { a = (uint32_t)mask0; b = (uint32_t)slot | ((uint32_t)n << 10) | ((uint32_t)mod << 20) | ((uint32_t)path << 23); }
+    else { a = (uint32_t)path | ((uint32_t)slot << 16); b = (uint32_t)n | ((uint32_t)mod << 16); }
+}
+template <bool R32> __device__ __forceinline__ int rec_path(uint32_t a, uint32_t b) { return R32 ? (int)(b >> 23) : (int)(a & 0xFFFF); }
+template <bool R32> __device__ __forceinline__ int rec_slot(uint32_t a, uint32_t b) { return R32 ? (int)(b & 0x3FF) : (int)(a >> 16); }
+template <bool R32> __device__ __forceinline__ int rec_n(uint32_t a, uint32_t b) { return R32 ? (int)((b >> 10) & 0x3FF) : (int)(b & 0xFFFF); }
+template <bool R32> __device__ __forceinline__ int rec_mod(uint32_t a, uint32_t b) { return R32 ? (int)((b >> 20) & 0x7) : (int)((b >> 16) & 0xFF); }
+
 // A path as the wave sees it: lane h holds link h.
 struct PathRef {
     int id, hops;
@@ -313,8 +329,23 @@ __device__ __forceinline__ void mark_links(Ctx &c, int hops, int mylink, int lo,
     __syncthreads();
 }
 
+// same, for a path given as a link mask (links < 32): lane l owns link l.
+__device__ __forceinline__ void mark_mask(Ctx &c, uint32_t mask, int lo, int hi, bool free_) {
+    const Params &P = c.P;
+    if (hi > P.n_slots) hi = P.n_slots;
+    if (c.lane < 32 && ((mask >> c.lane) & 1u) && hi > lo) {
+        for (int w = lo >> 6; w <= (hi - 1) >> 6; w++) {
+            uint64_t m = word_range(w, lo, hi);
+            uint64_t v = c.occ[c.lane * P.row_words + w];
+            c.occ[c.lane * P.row_words + w] = free_ ? (v | m) : (v & ~m);
+        }
+    }
+    __syncthreads();
+}
+
 // ---- GN model (core/osnr.pyx:21-142) ----------------------------------------------------------------------------
 // pass 1: compact the indices of the running services that share >= 1 link with the candidate path.
+template <bool R32>
 __device__ __forceinline__ int gn_build_list(Ctx &c, uint64_t cm0, uint64_t cm1) {
     const Params &P = c.P;
     int L = 0;
@@ -322,8 +353,11 @@ __device__ __forceinline__ int gn_build_list(Ctx &c, uint64_t cm0, uint64_t cm1)
         int i = base + c.lane;
         bool ov = false;
         if (i < c.active) {
-            int pk = c.sa[i] & 0xFFFF;
-            ov = ((P.path_mask[2 * pk] & cm0) | (P.path_mask[2 * pk + 1] & cm1)) != 0;
+            if (R32) ov = (c.sa[i] & (uint32_t)cm0) != 0;
+            else {
+                int pk = c.sa[i] & 0xFFFF;
+                ov = ((P.path_mask[2 * pk] & cm0) | (P.path_mask[2 * pk + 1] & cm1)) != 0;
+            }
         }
         uint64_t bal = __ballot(ov);
         if (ov) c.list[L + __popcll((unsigned long long)(bal & lanes_below(c.lane)))] = (uint16_t)i;
@@ -345,7 +379,7 @@ struct GnLin {          // noise-to-signal ratios in the linear domain (wave-uni
 // pass 2: 1/SNR_ase and 1/SNR_nli of a candidate lightpath (path, slot s, n slots) against the compacted interferers.
 // Span-hoisted: every span of a link is identical (topology.pyx:288-299), so the per-span sums of core/osnr.pyx:50-135
 // collapse to per-link weights w1 = nspans*l_eff, w2 = nspans*l_eff*l_eff/(L*1e3) (quirk Q11).
-template <bool UNIFORM_ALPHA>
+template <bool UNIFORM_ALPHA, bool R32>
 __device__ __forceinline__ GnLin gn_eval(Ctx &c, const PathRef &p, int L, int s, int n, double launch_power) {
     const Params &P = c.P;
     const double bw = P.slot_bw * n;
@@ -361,8 +395,10 @@ __device__ __forceinline__ GnLin gn_eval(Ctx &c, const PathRef &p, int L, int s,
     for (int j = c.lane; j < L; j += kWave) {
         int idx = c.list[j];
         uint32_t a = c.sa[idx], b = c.sb[idx];
-        int pk = a & 0xFFFF, sk = a >> 16, nk = b & 0xFFFF, mk = (b >> 16) & 0xFF;
-        uint64_t m0 = P.path_mask[2 * pk] & p.m0, m1 = P.path_mask[2 * pk + 1] & p.m1;
+        int sk = rec_slot<R32>(a, b), nk = rec_n<R32>(a, b), mk = rec_mod<R32>(a, b);
+        uint64_t m0, m1;
+        if (R32) { m0 = a & (uint32_t)p.m0; m1 = 0; }
+        else { int pk = a & 0xFFFF; m0 = P.path_mask[2 * pk] & p.m0; m1 = P.path_mask[2 * pk + 1] & p.m1; }
         double bk = P.slot_bw * nk;
         int dfi = (2 * sk + nk) - c2;                      // centre distance in half-slots (exact)
         double adf = (0.5 * P.slot_bw) * (double)abs(dfi); // |fc_k - fc|
@@ -430,17 +466,18 @@ struct Choice {
     int action, route, mod, slot, n, path;
     int flags;          // ONGYM_F_BLOCKED_*
     int hops, mylink;   // chosen path as lanes see it
+    uint64_t m0;        // its link mask (low word)
     GnLin g;
 };
 
 // ---- heuristic_shortest_available_path_first_fit_best_modulation (heuristics/heuristics.py:923-966) -----------
-template <bool UNIFORM_ALPHA>
+template <bool UNIFORM_ALPHA, bool R32>
 __device__ __forceinline__ void policy_first_fit(Ctx &c, int src, int dst, double launch_power, double margin,
                                                  Choice &ch) {
     const Params &P = c.P;
     const int M = P.n_mods, S = P.n_slots, max_mod = M - 1;
     ch.action = P.k_paths * M * S; ch.route = -1; ch.mod = -1; ch.slot = -1; ch.n = 0; ch.hops = 0; ch.mylink = 0;
-    ch.path = -1; ch.g.ase = ch.g.nli = 0.0;
+    ch.path = -1; ch.m0 = 0; ch.g.ase = ch.g.nli = 0.0;
     int bres = 0, bosnr = 0;
     for (int k = 0; k < P.k_paths; k++) {
         int path = k == 0 ? c.pre_id : P.pair_paths[(src * P.n_nodes + dst) * P.k_paths + k];
@@ -477,14 +514,14 @@ __device__ __forceinline__ void policy_first_fit(Ctx &c, int src, int dst, doubl
                 }
                 if (uniform_i32(lb >= c.lim[m] * (1.0 + 1e-9))) { bosnr = 1; bres = 0; c.gn_skips++; continue; }
             }
-            if (L < 0) { L = gn_build_list(c, p.m0, p.m1); STAMP(c, 3); }
-            GnLin g = gn_eval<UNIFORM_ALPHA>(c, p, L, first, n, launch_power);
+            if (L < 0) { L = gn_build_list<R32>(c, p.m0, p.m1); STAMP(c, 3); }
+            GnLin g = gn_eval<UNIFORM_ALPHA, R32>(c, p, L, first, n, launch_power);
             int ok = qot_ok(c, g, m, margin);
             STAMP(c, 4);
             if (ok) {
                 ch.action = k * M * S + (max_mod - m) * S + first;   // get_action_index, heuristics.py:36-54
                 ch.route = k; ch.mod = m; ch.slot = first; ch.n = n; ch.hops = p.hops; ch.mylink = p.mylink;
-                ch.path = path;
+                ch.path = path; ch.m0 = p.m0;
                 ch.g.ase = uniform_f64(g.ase); ch.g.nli = uniform_f64(g.nli);
                 ch.flags = 0;
                 return;
@@ -498,13 +535,13 @@ __device__ __forceinline__ void policy_first_fit(Ctx &c, int src, int dst, doubl
 
 // ---- decode + validate an external action (envs/qrmsa.pyx:801-834, 867-909) ------------------------------------
 // returns 0 accept (GN evaluated, passes), 1 reject action, 2 slots not free (retry), 3 QoT infeasible
-template <bool UNIFORM_ALPHA>
+template <bool UNIFORM_ALPHA, bool R32>
 __device__ __forceinline__ int evaluate_action(Ctx &c, int src, int dst, double launch_power, double margin,
                                                int action, Choice &ch) {
     const Params &P = c.P;
     const int M = P.n_mods, S = P.n_slots, max_mod = M - 1;
     ch.action = action; ch.route = -1; ch.mod = -1; ch.slot = -1; ch.n = 0; ch.flags = 0; ch.hops = 0; ch.mylink = 0;
-    ch.path = -1; ch.g.ase = ch.g.nli = 0.0;
+    ch.path = -1; ch.m0 = 0; ch.g.ase = ch.g.nli = 0.0;
     if (action == P.k_paths * M * S) return 1;
     if (action < 0 || action > P.k_paths * M * S) return 2;
     int slot = action % S; int t = action / S;
@@ -517,13 +554,13 @@ __device__ __forceinline__ int evaluate_action(Ctx &c, int src, int dst, double 
     ch.n = n; ch.path = path;
     if (path < 0 || n <= 0) return 2;
     PathRef p = load_path(c, path);
-    ch.hops = p.hops; ch.mylink = p.mylink;
+    ch.hops = p.hops; ch.mylink = p.mylink; ch.m0 = p.m0;
     int rr = 1;
     uint64_t ok_starts = run_and(path_free_ext(c, p), rr, n + 1);     // is_path_free, envs/qrmsa.pyx:1248-1264
     uint64_t w = readlane_u64(ok_starts, uniform_i32(slot >> 6));
     if (!((w >> (slot & 63)) & 1ull)) return 2;
-    int L = gn_build_list(c, p.m0, p.m1);
-    GnLin g = gn_eval<UNIFORM_ALPHA>(c, p, L, slot, n, launch_power);
+    int L = gn_build_list<R32>(c, p.m0, p.m1);
+    GnLin g = gn_eval<UNIFORM_ALPHA, R32>(c, p, L, slot, n, launch_power);
     ch.g.ase = uniform_f64(g.ase); ch.g.nli = uniform_f64(g.nli);
     return qot_ok(c, g, m, margin) ? 0 : 3;
 }
@@ -531,6 +568,7 @@ __device__ __forceinline__ int evaluate_action(Ctx &c, int src, int dst, double 
 // ---- departures: release every running service with float32 key <= now (envs/qrmsa.pyx:1113-1122, 1332-1350) ---
 // Set semantics are identical to the heap loop because float32 rounding is monotone. Removal = move the last record
 // into the hole; processing holes from the highest index down keeps every record above the hole a keeper.
+template <bool R32>
 __device__ __forceinline__ void release_due(Ctx &c, float now) {
     const Params &P = c.P;
     if (!(c.min_rel <= now)) return;
@@ -544,10 +582,14 @@ __device__ __forceinline__ void release_due(Ctx &c, float now) {
             bal &= ~(1ull << ln);
             int idx = ch * kWave + ln;
             uint32_t a = c.sa[idx], b = c.sb[idx];
-            int pk = a & 0xFFFF, sk = a >> 16, nk = b & 0xFFFF;
-            int hops = P.path_hops[pk];
-            int mylink = (c.lane < hops) ? P.path_links[pk * P.max_hops + c.lane] : 0;
-            mark_links(c, hops, mylink, sk, sk + nk + 1, true);   // frees n+1 slots, clamped at S (quirk Q7)
+            int sk = rec_slot<R32>(a, b), nk = rec_n<R32>(a, b);
+            if (R32) mark_mask(c, a, sk, sk + nk + 1, true);       // frees n+1 slots, clamped at S (quirk Q7)
+            else {
+                int pk = a & 0xFFFF;
+                int hops = P.path_hops[pk];
+                int mylink = (c.lane < hops) ? P.path_links[pk * P.max_hops + c.lane] : 0;
+                mark_links(c, hops, mylink, sk, sk + nk + 1, true);
+            }
             int last = c.active - 1;
             if (c.lane == 0 && idx != last) { c.sa[idx] = c.sa[last]; c.sb[idx] = c.sb[last]; c.sr[idx] = c.sr[last]; }
             c.active = last;
@@ -684,6 +726,7 @@ __device__ __forceinline__ void snapshot_terminal(DevEnv *e) {   // info of the 
 
 // ---- one request: apply the choice (envs/qrmsa.pyx:838-1065) ----------------------------------------------------
 // outcome: 0 = accept & provision, 1 = reject action, 2 = retry (slots busy), 3 = QoT error
+template <bool R32>
 __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome, ongym_step_rec *rec) {
     const Params &P = c.P;
     DevEnv *e = c.e;
@@ -727,8 +770,9 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
             double g[3] = {10.0 * log10(1.0 / (ch.g.ase + ch.g.nli)), 0.0, 0.0};   // Service.OSNR (once per step)
             if (rec) { g[1] = 10.0 * log10(1.0 / ch.g.ase); g[2] = 10.0 * log10(1.0 / ch.g.nli); }
             rel = e->cur_at + e->cur_ht;   // float + float (:1329); compared as float32 (:1114-1115)
-            c.sa[c.active] = (uint32_t)ch.path | ((uint32_t)ch.slot << 16);
-            c.sb[c.active] = (uint32_t)ch.n | ((uint32_t)ch.mod << 16);
+            uint32_t ra, rb;
+            rec_pack<R32>(ch.path, ch.m0, ch.slot, ch.n, ch.mod, ra, rb);
+            c.sa[c.active] = ra; c.sb[c.active] = rb;
             c.sr[c.active] = rel;
             s.services_accepted += 1; s.episode_services_accepted += 1;
             s.bit_rate_provisioned += (double)e->cur_br;
@@ -761,7 +805,7 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
     __syncthreads();
     draw_next(c);                                 // first half of _next_service (:1079-1111)
     STAMP(c, 6);
-    release_due(c, e->cur_at);                    // second half of _next_service (:1113-1122)
+    release_due<R32>(c, e->cur_at);               // second half of _next_service (:1113-1122)
     STAMP(c, 7);
     int terminated = e->st.episode_services_processed == P.episode_length;
     if (c.lane == 0) {

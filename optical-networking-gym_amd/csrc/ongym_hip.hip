@@ -16,7 +16,7 @@ using namespace ongym;
 // ---------------------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------------------
-template <bool UA>
+template <bool UA, bool R32>
 __global__ __launch_bounds__(64, 4) void k_run(const Params *__restrict__ Pp, int mode, int nsteps, const int32_t *actions, int32_t *act_out,
                                             uint8_t *flag_out, ongym_step_rec *out) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -56,16 +56,16 @@ __global__ __launch_bounds__(64, 4) void k_run(const Params *__restrict__ Pp, in
         Choice ch;
         int outcome;
         if (mode == kModeActionStep) {
-            outcome = evaluate_action<UA>(c, src, dst, lp, mg, actions[c.replica], ch);
+            outcome = evaluate_action<UA, R32>(c, src, dst, lp, mg, actions[c.replica], ch);
         } else {
-            policy_first_fit<UA>(c, src, dst, lp, mg, ch);
+            policy_first_fit<UA, R32>(c, src, dst, lp, mg, ch);
             outcome = ch.route >= 0 ? 0 : 1;
         }
         if (mode == kModePolicyOnly) {
             if (c.lane == 0) { act_out[c.replica] = ch.action; if (flag_out) flag_out[c.replica] = (uint8_t)ch.flags; }
             continue;
         }
-        apply_step(c, ch, outcome, rec);
+        apply_step<R32>(c, ch, outcome, rec);
     }
     if (mode != kModePolicyOnly) store_state(c);
     STAMP(c, 9);
@@ -107,7 +107,7 @@ __global__ void k_rewind(Params P) {   // new trace: cursor back to 0
 
 enum { kQAvailable = 0, kQGsnr = 1, kQGrid = 2, kQServices = 3, kQRequest = 4, kQCandidates = 5, kQPathFree = 6 };
 
-template <bool UA>
+template <bool UA, bool R32>
 __global__ __launch_bounds__(64) void k_query(const Params *__restrict__ Pp, int what, int replica, int path, int slot, int n,
                                               int32_t *out_i, double *out_d) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -130,8 +130,8 @@ __global__ __launch_bounds__(64) void k_query(const Params *__restrict__ Pp, int
         }
     } else if (what == kQGsnr) {        // calculate_osnr(env, candidate), core/osnr.pyx:21-142
         PathRef p = load_path(c, path);
-        int L = gn_build_list(c, p.m0, p.m1);
-        GnLin lin = gn_eval<UA>(c, p, L, slot, n, c.e->launch_power);
+        int L = gn_build_list<R32>(c, p.m0, p.m1);
+        GnLin lin = gn_eval<UA, R32>(c, p, L, slot, n, c.e->launch_power);
         double g[3];
         gn_to_db(lin, g);
         if (c.lane == 0) { out_d[0] = g[0]; out_d[1] = g[1]; out_d[2] = g[2]; }
@@ -145,8 +145,9 @@ __global__ __launch_bounds__(64) void k_query(const Params *__restrict__ Pp, int
         if (c.lane == 0) out_i[0] = c.active;
         for (int i = c.lane; i < c.active; i += kWave) {
             uint32_t a = c.sa[i], b = c.sb[i];
-            o[i].path_id = a & 0xFFFF; o[i].slot = (int16_t)(a >> 16); o[i].nslots = (int16_t)(b & 0xFFFF);
-            o[i].modulation = (int16_t)((b >> 16) & 0xFF); o[i].reserved = 0; o[i].release_time = c.sr[i];
+            o[i].path_id = rec_path<R32>(a, b); o[i].slot = (int16_t)rec_slot<R32>(a, b);
+            o[i].nslots = (int16_t)rec_n<R32>(a, b); o[i].modulation = (int16_t)rec_mod<R32>(a, b);
+            o[i].reserved = 0; o[i].release_time = c.sr[i];
         }
     } else if (what == kQCandidates) {  // _get_candidates on a caller-supplied row: path = total_slots, n = nslots
         const int total = path;
@@ -299,6 +300,7 @@ static int build(ongym_env *env, const ongym_config *c) {
         if (a != c->link_alpha[0]) uniform = false;
     }
     P.uniform_alpha = uniform ? 1 : 0;
+    P.rec32 = (E <= 32 && NP <= 512 && c->n_slots <= 1023) ? 1 : 0;
     P.alpha0_cl = cl[0];
     std::vector<uint64_t> mask((size_t)NP * 2, 0);
     std::vector<double> path_ase(NP, 0.0), path_w1(NP, 0.0);
@@ -441,11 +443,13 @@ static int build(ongym_env *env, const ongym_config *c) {
     env->lds = lds_bytes(E, P.row_words, c->capacity);
     if (env->lds > 64 * 1024) {
         if (env->lds > 160 * 1024) return fail_arg(env, "state does not fit the 160 KiB LDS: lower capacity", ONGYM_E_LIMIT);
-        HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_run<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->lds));
-        HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_run<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->lds));
-        HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_reset), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->lds));
-        HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_query<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->lds));
-        HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_query<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->lds));
+#define ONGYM_SET_LDS(K) HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->lds))
+        ONGYM_SET_LDS((k_run<true, true>)); ONGYM_SET_LDS((k_run<true, false>));
+        ONGYM_SET_LDS((k_run<false, true>)); ONGYM_SET_LDS((k_run<false, false>));
+        ONGYM_SET_LDS((k_query<true, true>)); ONGYM_SET_LDS((k_query<true, false>));
+        ONGYM_SET_LDS((k_query<false, true>)); ONGYM_SET_LDS((k_query<false, false>));
+        ONGYM_SET_LDS(k_reset);
+#undef ONGYM_SET_LDS
     }
     // scratch for queries / host-buffer I/O
     env->scratch_i_bytes = std::max(std::max((size_t)E * c->n_slots * 4, (size_t)c->capacity * sizeof(ongym_service) + 16), (size_t)2048 * 4);
@@ -602,12 +606,13 @@ int ongym_reset(ongym_env *env, const uint8_t *mask) {
 static int launch_run(ongym_env *env, int mode, int nsteps, const int32_t *d_actions, int32_t *d_act_out,
                       uint8_t *d_flag_out, ongym_step_rec *d_out) {
     HIP_TRY(env, hipEventRecord(env->ev0, env->stream));
-    if (env->P.uniform_alpha)
-        hipLaunchKernelGGL(k_run<true>, dim3(env->P.batch), dim3(64), env->lds, env->stream, env->d_P, mode, nsteps,
-                           d_actions, d_act_out, d_flag_out, d_out);
-    else
-        hipLaunchKernelGGL(k_run<false>, dim3(env->P.batch), dim3(64), env->lds, env->stream, env->d_P, mode, nsteps,
-                           d_actions, d_act_out, d_flag_out, d_out);
+    const dim3 grid(env->P.batch), block(64);
+#define ONGYM_LAUNCH_RUN(UA, R)                                                                                    \
+    hipLaunchKernelGGL((k_run<UA, R>), grid, block, env->lds, env->stream, env->d_P, mode, nsteps, d_actions,       \
+                       d_act_out, d_flag_out, d_out)
+    if (env->P.uniform_alpha) { if (env->P.rec32) ONGYM_LAUNCH_RUN(true, true); else ONGYM_LAUNCH_RUN(true, false); }
+    else { if (env->P.rec32) ONGYM_LAUNCH_RUN(false, true); else ONGYM_LAUNCH_RUN(false, false); }
+#undef ONGYM_LAUNCH_RUN
     HIP_TRY(env, hipGetLastError());
     HIP_TRY(env, hipEventRecord(env->ev1, env->stream));
     env->timed = true;
@@ -676,10 +681,12 @@ static int query(ongym_env *env, int what, int replica, int path, int slot, int 
     if (what == kQPathFree && (slot < 0 || n <= 0 || slot >= env->P.n_slots || n > 1023)) return fail_arg(env, "slot / nslots out of range");
     if (what == kQCandidates && (path <= 0 || path > 1023 || n <= 0 || n > 1023)) return fail_arg(env, "total_slots / nslots out of range");
     HIP_TRY(env, hipSetDevice(env->cfg.device));
-    if (env->P.uniform_alpha)
-        hipLaunchKernelGGL(k_query<true>, dim3(1), dim3(64), env->lds, env->stream, env->d_P, what, replica, path, slot, n, env->d_scratch_i, env->d_scratch_d);
-    else
-        hipLaunchKernelGGL(k_query<false>, dim3(1), dim3(64), env->lds, env->stream, env->d_P, what, replica, path, slot, n, env->d_scratch_i, env->d_scratch_d);
+#define ONGYM_LAUNCH_Q(UA, R)                                                                                       \
+    hipLaunchKernelGGL((k_query<UA, R>), dim3(1), dim3(64), env->lds, env->stream, env->d_P, what, replica, path,   \
+                       slot, n, env->d_scratch_i, env->d_scratch_d)
+    if (env->P.uniform_alpha) { if (env->P.rec32) ONGYM_LAUNCH_Q(true, true); else ONGYM_LAUNCH_Q(true, false); }
+    else { if (env->P.rec32) ONGYM_LAUNCH_Q(false, true); else ONGYM_LAUNCH_Q(false, false); }
+#undef ONGYM_LAUNCH_Q
     HIP_TRY(env, hipGetLastError());
     return 0;
 }
