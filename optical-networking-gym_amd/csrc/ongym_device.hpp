@@ -72,6 +72,7 @@ struct Params {
     const double *link_selfc;       // [E]    pi^2 |beta2| / (4 alpha)
     const double *path_w1;          // [P]    sum_l w1_l over the path's links (uniform-alpha self term)
     const double *self_asinh;       // [S+1]  asinh(pi^2 |b2| (slot_bw n)^2 / (4 alpha)) when alpha is uniform
+    const double *nli_coef;         // [S+2]  8/(27 pi |b2|) gamma^2 / (slot_bw n)^2   (P_nli/P = nli_coef[n] * P^2 * sum)
     const double2 *pair_tab;        // [tab_nmax][2S+1] (asinh difference, Bk/|df|) by (interferer slots, centre distance in
                                     //  half slots), uniform alpha only; NULL = always compute
     int tab_nmax, tab_stride;
@@ -93,11 +94,11 @@ struct Params {
 // ---------------------------------------------------------------------------------------------------------------
 // LDS carve-up (dynamic shared memory), 8-byte aligned pieces first
 //   occ u64[E*W] | lw1 f64[E] | lw2 f64[E] | lcl f64[E] | lsc f64[E] | DevEnv | sa u32[C] | sb u32[C] | sr f32[C] |
-//   lim f64[8] | nreq i32[8] | list u16[C]
+//   lim f64[8] | rp f64[2] | nreq i32[8] | list u16[C]
 // ---------------------------------------------------------------------------------------------------------------
 __host__ __device__ inline size_t lds_bytes(int n_links, int row_words, int capacity) {
     size_t b = (size_t)n_links * row_words * 8 + (size_t)n_links * 32 + ((sizeof(DevEnv) + 7) & ~(size_t)7);
-    b += (size_t)capacity * 12 + 64 + 32 + (size_t)capacity * 2;
+    b += (size_t)capacity * 12 + 64 + 16 + 32 + (size_t)capacity * 2;
     return (b + 15) & ~(size_t)15;
 }
 
@@ -128,6 +129,7 @@ struct Ctx {
     float *sr;
     int *nreq;
     double *lim;       // LDS [8] linear-domain acceptance limits 10^(-(thr_m+margin)/10) of this replica
+    double *rp;        // LDS [2] 1/launch_power, launch_power^2 of this replica
     uint16_t *list;
     double node_cum_reg;   // node_cum[lane] (+inf beyond n_nodes) when n_nodes <= 64
     double br_cum_reg;     // bit_rate_cum[lane] (+inf beyond n_bit_rates)
@@ -158,8 +160,16 @@ __device__ __forceinline__ void ctx_bind(Ctx &c, unsigned char *smem) {
     c.sb = c.sa + P.capacity;
     c.sr = reinterpret_cast<float *>(c.sb + P.capacity);
     c.lim = reinterpret_cast<double *>(c.sr + P.capacity);   // capacity is a multiple of 64 -> 8-byte aligned
-    c.nreq = reinterpret_cast<int *>(c.lim + 8);
+    c.rp = c.lim + 8;
+    c.nreq = reinterpret_cast<int *>(c.rp + 2);
     c.list = reinterpret_cast<uint16_t *>(c.nreq + 8);
+}
+
+// Table pointers live in a Params object read from memory, so the compiler cannot know they are global and would emit
+// flat_load (which also ties up the LDS counter). G() states the address space.
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(1))) T *G(const T *p) {
+    return (const __attribute__((address_space(1))) T *)p;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -280,13 +290,13 @@ struct PathRef {
 
 __device__ __forceinline__ void prefetch_first_path(Ctx &c, int src, int dst) {
     const Params &P = c.P;
-    int path = P.pair_paths[(src * P.n_nodes + dst) * P.k_paths];
+    int path = G(P.pair_paths)[(src * P.n_nodes + dst) * P.k_paths];
     c.pre_id = path;
     if (path >= 0) {
-        c.pre_hops = P.path_hops[path];
-        c.pre_mylink = (c.lane < c.pre_hops) ? P.path_links[path * P.max_hops + c.lane] : 0;
-        c.pre_m0 = P.path_mask[2 * path];
-        c.pre_m1 = P.path_mask[2 * path + 1];
+        c.pre_hops = G(P.path_hops)[path];
+        c.pre_mylink = (c.lane < c.pre_hops) ? G(P.path_links)[path * P.max_hops + c.lane] : 0;
+        c.pre_m0 = G(P.path_mask)[2 * path];
+        c.pre_m1 = G(P.path_mask)[2 * path + 1];
     }
 }
 
@@ -294,10 +304,10 @@ __device__ __forceinline__ PathRef load_path(const Ctx &c, int path) {
     const Params &P = c.P;
     PathRef r;
     r.id = path;
-    r.hops = P.path_hops[path];
-    r.mylink = (c.lane < r.hops) ? P.path_links[path * P.max_hops + c.lane] : 0;
-    r.m0 = P.path_mask[2 * path];
-    r.m1 = P.path_mask[2 * path + 1];
+    r.hops = G(P.path_hops)[path];
+    r.mylink = (c.lane < r.hops) ? G(P.path_links)[path * P.max_hops + c.lane] : 0;
+    r.m0 = G(P.path_mask)[2 * path];
+    r.m1 = G(P.path_mask)[2 * path + 1];
     return r;
 }
 
@@ -356,7 +366,7 @@ __device__ __forceinline__ int gn_build_list(Ctx &c, uint64_t cm0, uint64_t cm1)
             if (R32) ov = (c.sa[i] & (uint32_t)cm0) != 0;
             else {
                 int pk = c.sa[i] & 0xFFFF;
-                ov = ((P.path_mask[2 * pk] & cm0) | (P.path_mask[2 * pk + 1] & cm1)) != 0;
+                ov = ((G(P.path_mask)[2 * pk] & cm0) | (G(P.path_mask)[2 * pk + 1] & cm1)) != 0;
             }
         }
         uint64_t bal = __ballot(ov);
@@ -380,14 +390,14 @@ struct GnLin {          // noise-to-signal ratios in the linear domain (wave-uni
 // Span-hoisted: every span of a link is identical (topology.pyx:288-299), so the per-span sums of core/osnr.pyx:50-135
 // collapse to per-link weights w1 = nspans*l_eff, w2 = nspans*l_eff*l_eff/(L*1e3) (quirk Q11).
 template <bool UNIFORM_ALPHA, bool R32>
-__device__ __forceinline__ GnLin gn_eval(Ctx &c, const PathRef &p, int L, int s, int n, double launch_power) {
+__device__ __forceinline__ GnLin gn_eval(Ctx &c, const PathRef &p, int L, int s, int n) {
     const Params &P = c.P;
     const double bw = P.slot_bw * n;
     const int c2 = 2 * s + n;  // candidate centre in half-slots
     double part = 0.0;
     // self-channel term asinh(pi^2 |b2| B^2 / (4 alpha)) per link (core/osnr.pyx:58-61)
     if (UNIFORM_ALPHA) {
-        if (c.lane == 0) part = P.path_w1[p.id] * P.self_asinh[n];
+        if (c.lane == 0) part = G(P.path_w1)[p.id] * G(P.self_asinh)[n];
     } else {
         if (c.lane < p.hops) part = c.lw1[p.mylink] * asinh(c.lsc[p.mylink] * (bw * bw));
     }
@@ -398,7 +408,7 @@ __device__ __forceinline__ GnLin gn_eval(Ctx &c, const PathRef &p, int L, int s,
         int sk = rec_slot<R32>(a, b), nk = rec_n<R32>(a, b), mk = rec_mod<R32>(a, b);
         uint64_t m0, m1;
         if (R32) { m0 = a & (uint32_t)p.m0; m1 = 0; }
-        else { int pk = a & 0xFFFF; m0 = P.path_mask[2 * pk] & p.m0; m1 = P.path_mask[2 * pk + 1] & p.m1; }
+        else { int pk = a & 0xFFFF; m0 = G(P.path_mask)[2 * pk] & p.m0; m1 = G(P.path_mask)[2 * pk + 1] & p.m1; }
         double bk = P.slot_bw * nk;
         int dfi = (2 * sk + nk) - c2;                      // centre distance in half-slots (exact)
         double adf = (0.5 * P.slot_bw) * (double)abs(dfi); // |fc_k - fc|
@@ -410,9 +420,9 @@ __device__ __forceinline__ GnLin gn_eval(Ctx &c, const PathRef &p, int L, int s,
             double A;
             int adi = abs(dfi);
             if (nk <= P.tab_nmax) {   // (asinh difference, Bk/|df|) depend on two small integers only: one 16-byte gather
-                double2 t = P.pair_tab[(nk - 1) * P.tab_stride + adi];
-                A = t.x;
-                corr = P.mod_phi53[mk] * t.y;
+                const auto *t = G(reinterpret_cast<const double *>(P.pair_tab)) + 2 * ((nk - 1) * P.tab_stride + adi);
+                A = t[0];
+                corr = P.mod_phi53[mk] * t[1];
             } else {
                 double ck = P.alpha0_cl * bk;
                 A = asinh_diff(ck * hi, ck * lo);
@@ -434,20 +444,19 @@ __device__ __forceinline__ GnLin gn_eval(Ctx &c, const PathRef &p, int L, int s,
     c.lane_terms += terms;
     c.gn_evals++;
     double total = wave_sum(part);
-    const double pi = 3.14159265358979323846, beta2 = 21.3e-27, gamma = 1.3e-3;
-    double ratio = launch_power / bw;
-    double knli = (ratio * ratio * ratio) * (8.0 / (27.0 * pi * beta2)) * (gamma * gamma) * bw;
+    // P_nli/P = (P/B)^3 * 8/(27 pi |b2|) * gamma^2 * B / P * sum = nli_coef[n] * P^2 * sum   (core/osnr.pyx:109-116,135)
+    // P_ase/P = B * h * fc * sum_l n_l (exp(2 a L) - 1) NF / P                                 (core/osnr.pyx:119-125,134)
     double fc = P.f0 + (P.slot_bw * s) + (P.slot_bw * (n / 2.0));  // envs/qrmsa.pyx:901-905
     GnLin g;
-    g.nli = knli * total / launch_power;
-    g.ase = bw * fc * P.path_ase[p.id] / launch_power;
+    g.nli = (G(P.nli_coef)[n] * c.rp[1]) * total;
+    g.ase = (bw * fc * G(P.path_ase)[p.id]) * c.rp[0];
     return g;
 }
 
 __device__ __forceinline__ void gn_to_db(const GnLin &g, double out[3]) {   // core/osnr.pyx:138-140
-    out[0] = 10.0 * log10(1.0 / (g.ase + g.nli));
-    out[1] = 10.0 * log10(1.0 / g.ase);
-    out[2] = 10.0 * log10(1.0 / g.nli);
+    out[0] = -10.0 * log10(g.ase + g.nli);   // = 10 log10(1/acc)
+    out[1] = -10.0 * log10(g.ase);
+    out[2] = -10.0 * log10(g.nli);
 }
 
 // GSNR >= minimum_osnr + margin ?  (heuristics.py:957-958, envs/qrmsa.pyx:911). The comparison is made in the linear
@@ -480,7 +489,7 @@ __device__ __forceinline__ void policy_first_fit(Ctx &c, int src, int dst, doubl
     ch.path = -1; ch.m0 = 0; ch.g.ase = ch.g.nli = 0.0;
     int bres = 0, bosnr = 0;
     for (int k = 0; k < P.k_paths; k++) {
-        int path = k == 0 ? c.pre_id : P.pair_paths[(src * P.n_nodes + dst) * P.k_paths + k];
+        int path = k == 0 ? c.pre_id : G(P.pair_paths)[(src * P.n_nodes + dst) * P.k_paths + k];
         if (path < 0) break;
         PathRef p;
         if (k == 0) { p.id = path; p.hops = c.pre_hops; p.mylink = c.pre_mylink; p.m0 = c.pre_m0; p.m1 = c.pre_m1; }
@@ -505,17 +514,12 @@ __device__ __forceinline__ void policy_first_fit(Ctx &c, int src, int dst, doubl
                 // gn_eval, same 1e-9 guard band as qot_ok).
                 double bw = P.slot_bw * n;
                 double fc = P.f0 + (P.slot_bw * first) + (P.slot_bw * (n / 2.0));
-                double lb = bw * fc * P.path_ase[path] / launch_power;
-                if (UNIFORM_ALPHA) {
-                    const double pi = 3.14159265358979323846, beta2 = 21.3e-27, gamma = 1.3e-3;
-                    double ratio = launch_power / bw;
-                    double knli = (ratio * ratio * ratio) * (8.0 / (27.0 * pi * beta2)) * (gamma * gamma) * bw;
-                    lb += knli * (P.path_w1[path] * P.self_asinh[n]) / launch_power;
-                }
+                double lb = (bw * fc * G(P.path_ase)[path]) * c.rp[0];
+                if (UNIFORM_ALPHA) lb += (G(P.nli_coef)[n] * c.rp[1]) * (G(P.path_w1)[path] * G(P.self_asinh)[n]);
                 if (uniform_i32(lb >= c.lim[m] * (1.0 + 1e-9))) { bosnr = 1; bres = 0; c.gn_skips++; continue; }
             }
             if (L < 0) { L = gn_build_list<R32>(c, p.m0, p.m1); STAMP(c, 3); }
-            GnLin g = gn_eval<UNIFORM_ALPHA, R32>(c, p, L, first, n, launch_power);
+            GnLin g = gn_eval<UNIFORM_ALPHA, R32>(c, p, L, first, n);
             int ok = qot_ok(c, g, m, margin);
             STAMP(c, 4);
             if (ok) {
@@ -549,7 +553,7 @@ __device__ __forceinline__ int evaluate_action(Ctx &c, int src, int dst, double 
     int route = t % P.k_paths;
     int m = max_mod - r;   // allowed_mods = range(max_idx, max_idx-M, -1), max_idx = M-1 when gen_observation=False
     ch.route = route; ch.mod = m; ch.slot = slot;
-    int path = P.pair_paths[(src * P.n_nodes + dst) * P.k_paths + route];
+    int path = G(P.pair_paths)[(src * P.n_nodes + dst) * P.k_paths + route];
     int n = c.nreq[m];
     ch.n = n; ch.path = path;
     if (path < 0 || n <= 0) return 2;
@@ -560,7 +564,7 @@ __device__ __forceinline__ int evaluate_action(Ctx &c, int src, int dst, double 
     uint64_t w = readlane_u64(ok_starts, uniform_i32(slot >> 6));
     if (!((w >> (slot & 63)) & 1ull)) return 2;
     int L = gn_build_list<R32>(c, p.m0, p.m1);
-    GnLin g = gn_eval<UNIFORM_ALPHA, R32>(c, p, L, slot, n, launch_power);
+    GnLin g = gn_eval<UNIFORM_ALPHA, R32>(c, p, L, slot, n);
     ch.g.ase = uniform_f64(g.ase); ch.g.nli = uniform_f64(g.nli);
     return qot_ok(c, g, m, margin) ? 0 : 3;
 }
@@ -586,8 +590,8 @@ __device__ __forceinline__ void release_due(Ctx &c, float now) {
             if (R32) mark_mask(c, a, sk, sk + nk + 1, true);       // frees n+1 slots, clamped at S (quirk Q7)
             else {
                 int pk = a & 0xFFFF;
-                int hops = P.path_hops[pk];
-                int mylink = (c.lane < hops) ? P.path_links[pk * P.max_hops + c.lane] : 0;
+                int hops = G(P.path_hops)[pk];
+                int mylink = (c.lane < hops) ? G(P.path_links)[pk * P.max_hops + c.lane] : 0;
                 mark_links(c, hops, mylink, sk, sk + nk + 1, true);
             }
             int last = c.active - 1;
@@ -639,10 +643,10 @@ __device__ __forceinline__ void draw_next(Ctx &c) {
         ht = -l1 * P.mean_holding_f;
         const int n = P.n_nodes;
         const bool small = n <= kWave;
-        double total = small ? __shfl(c.node_cum_reg, n - 1) : P.node_cum[n - 1];
+        double total = small ? readlane_f64(c.node_cum_reg, n - 1) : P.node_cum[n - 1];
         src = cum_search(c, P.node_cum, c.node_cum_reg, n, u2 * total);
-        double hi_s = small ? __shfl(c.node_cum_reg, src) : P.node_cum[src];
-        double lo_s = src > 0 ? (small ? __shfl(c.node_cum_reg, src - 1) : P.node_cum[src - 1]) : 0.0;
+        double hi_s = small ? readlane_f64(c.node_cum_reg, src) : P.node_cum[src];
+        double lo_s = src > 0 ? (small ? readlane_f64(c.node_cum_reg, src - 1) : P.node_cum[src - 1]) : 0.0;
         double w_s = hi_s - lo_s;
         double x = u3 * (total - w_s);
         if (x >= lo_s) x += w_s;
@@ -650,9 +654,9 @@ __device__ __forceinline__ void draw_next(Ctx &c) {
         if (dst == src) dst = (src + 1 < n) ? src + 1 : src - 1;
         if (P.bit_rate_mode == 0) {
             const int nb = P.n_bit_rates;
-            double tb = nb <= kWave ? __shfl(c.br_cum_reg, nb - 1) : P.bit_rate_cum[nb - 1];
+            double tb = nb <= kWave ? readlane_f64(c.br_cum_reg, nb - 1) : P.bit_rate_cum[nb - 1];
             bi = cum_search(c, P.bit_rate_cum, c.br_cum_reg, nb, u4 * tb);
-            br = nb <= kWave ? __shfl(c.br_reg, bi) : (float)P.bit_rates[bi];
+            br = nb <= kWave ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.br_reg), bi)) : (float)P.bit_rates[bi];
         } else {
             int span = P.br_hi - P.br_lo + 1;
             int k = (int)(u4 * (double)span);
@@ -670,7 +674,7 @@ __device__ __forceinline__ void draw_next(Ctx &c) {
     // slots needed per modulation: get_number_slots (envs/qrmsa.pyx:1198-1205), lane m -> nreq[m]
     prefetch_first_path(c, src, dst);
     if (c.lane < P.n_mods)
-        c.nreq[c.lane] = bi >= 0 ? P.nreq_tab[bi * kMaxMods + c.lane]
+        c.nreq[c.lane] = bi >= 0 ? G(P.nreq_tab)[bi * kMaxMods + c.lane]
                                  : (int)ceil((double)br / ((double)P.mod_se[c.lane] * P.channel_width));
     if (c.lane == 0) {
         e->req_index++;
@@ -743,7 +747,7 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
                 r.reward = -3.0 * (1.0 + failed);   // reward(), :1266-1271
                 r.retry = 1; r.flags |= ONGYM_F_BLOCKED_RESOURCES;
             } else {
-                r.flags |= ONGYM_F_QOT_ERROR; r.osnr = 10.0 * log10(1.0 / (ch.g.ase + ch.g.nli));
+                r.flags |= ONGYM_F_QOT_ERROR; r.osnr = -10.0 * log10(ch.g.ase + ch.g.nli);
                 r.route = (int16_t)ch.route; r.slot = (int16_t)ch.slot;
             }
             *rec = r;
@@ -767,8 +771,8 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
         r.osnr = 0.0; r.ase = 0.0; r.nli = 0.0; r.reward = 0.0; r.active = 0;
         double osnr = 0.0;
         if (outcome == 0) {
-            double g[3] = {10.0 * log10(1.0 / (ch.g.ase + ch.g.nli)), 0.0, 0.0};   // Service.OSNR (once per step)
-            if (rec) { g[1] = 10.0 * log10(1.0 / ch.g.ase); g[2] = 10.0 * log10(1.0 / ch.g.nli); }
+            double g[3] = {-10.0 * log10(ch.g.ase + ch.g.nli), 0.0, 0.0};   // Service.OSNR = 10 log10(1/acc), once per step
+            if (rec) { g[1] = -10.0 * log10(ch.g.ase); g[2] = -10.0 * log10(ch.g.nli); }
             rel = e->cur_at + e->cur_ht;   // float + float (:1329); compared as float32 (:1114-1115)
             uint32_t ra, rb;
             rec_pack<R32>(ch.path, ch.m0, ch.slot, ch.n, ch.mod, ra, rb);
@@ -839,6 +843,7 @@ __device__ __forceinline__ void load_state(Ctx &c) {
     if (c.e->have_request) prefetch_first_path(c, c.e->cur_src, c.e->cur_dst);
     // per-replica acceptance limits in the linear domain (see qot_ok)
     if (c.lane < P.n_mods) c.lim[c.lane] = pow(10.0, -(P.mod_thr[c.lane] + c.e->margin) / 10.0);
+    if (c.lane == 0) { c.rp[0] = 1.0 / c.e->launch_power; c.rp[1] = c.e->launch_power * c.e->launch_power; }
     // slots needed by the current request (kept in LDS between requests, recomputed on load)
     if (c.lane < P.n_mods)
         c.nreq[c.lane] = (int)ceil((double)c.e->cur_br / ((double)P.mod_se[c.lane] * P.channel_width));

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64) void k_query(const Params *__restrict__ Pp, int
     } else if (what == kQGsnr) {        // calculate_osnr(env, candidate), core/osnr.pyx:21-142
         PathRef p = load_path(c, path);
         int L = gn_build_list<R32>(c, p.m0, p.m1);
-        GnLin lin = gn_eval<UA, R32>(c, p, L, slot, n, c.e->launch_power);
+        GnLin lin = gn_eval<UA, R32>(c, p, L, slot, n);
         double g[3];
         gn_to_db(lin, g);
         if (c.lane == 0) { out_d[0] = g[0]; out_d[1] = g[1]; out_d[2] = g[2]; }
@@ -311,6 +311,11 @@ static int build(ongym_env *env, const ongym_config *c) {
             path_ase[p] += ase_link[l];
             path_w1[p] += w1[l];
         }
+    std::vector<double> nli_coef((size_t)c->n_slots + 2, 0.0);
+    for (int n = 1; n <= c->n_slots + 1; n++) {
+        const double gamma = 1.3e-3, bwn = c->slot_bandwidth * n;
+        nli_coef[n] = (8.0 / (27.0 * pi * beta2)) * (gamma * gamma) / (bwn * bwn);
+    }
     std::vector<double> self_asinh((size_t)c->n_slots + 2, 0.0);   // uniform alpha only
     for (int n = 0; n <= c->n_slots + 1; n++) {
         double bwn = c->slot_bandwidth * n;
@@ -398,6 +403,7 @@ static int build(ongym_env *env, const ongym_config *c) {
     if ((rc = upload(env, path_ase.data(), path_ase.size(), &P.path_ase))) return rc;
     if ((rc = upload(env, path_w1.data(), path_w1.size(), &P.path_w1))) return rc;
     if ((rc = upload(env, self_asinh.data(), self_asinh.size(), &P.self_asinh))) return rc;
+    if ((rc = upload(env, nli_coef.data(), nli_coef.size(), &P.nli_coef))) return rc;
     if ((rc = upload(env, w1.data(), w1.size(), &P.link_w1))) return rc;
     if ((rc = upload(env, w2.data(), w2.size(), &P.link_w2))) return rc;
     if ((rc = upload(env, cl.data(), cl.size(), &P.link_cl))) return rc;
