@@ -94,11 +94,11 @@ struct Params {
 // ---------------------------------------------------------------------------------------------------------------
 // LDS carve-up (dynamic shared memory), 8-byte aligned pieces first
 //   occ u64[E*W] | lw1 f64[E] | lw2 f64[E] | lcl f64[E] | lsc f64[E] | DevEnv | sa u32[C] | sb u32[C] | sr f32[C] |
-//   lim f64[8] | rp f64[2] | nreq i32[8] | list u16[C]
+//   lim f64[8] | rp f64[2] | phi f64[8] | nreq i32[8] | list u16[C]
 // ---------------------------------------------------------------------------------------------------------------
 __host__ __device__ inline size_t lds_bytes(int n_links, int row_words, int capacity) {
     size_t b = (size_t)n_links * row_words * 8 + (size_t)n_links * 32 + ((sizeof(DevEnv) + 7) & ~(size_t)7);
-    b += (size_t)capacity * 12 + 64 + 16 + 32 + (size_t)capacity * 2;
+    b += (size_t)capacity * 12 + 64 + 16 + 64 + 32 + (size_t)capacity * 2;
     return (b + 15) & ~(size_t)15;
 }
 
@@ -130,6 +130,7 @@ struct Ctx {
     int *nreq;
     double *lim;       // LDS [8] linear-domain acceptance limits 10^(-(thr_m+margin)/10) of this replica
     double *rp;        // LDS [2] 1/launch_power, launch_power^2 of this replica
+    double *phi;       // LDS [8] Phi_mod * 5/3 per modulation
     uint16_t *list;
     double node_cum_reg;   // node_cum[lane] (+inf beyond n_nodes) when n_nodes <= 64
     double br_cum_reg;     // bit_rate_cum[lane] (+inf beyond n_bit_rates)
@@ -139,7 +140,6 @@ struct Ctx {
     int pre_id, pre_hops, pre_mylink;
     uint64_t pre_m0, pre_m1;
     int active;        // running services (wave-uniform, mirrored to e->st.active at store time)
-    float min_rel;     // wave-uniform
     int lane_terms;    // per-lane interferer-link term counter (reduced once per launch)
     int gn_evals;      // wave-uniform
     int gn_skips;      // wave-uniform: evaluations decided by the ASE-only bound
@@ -161,7 +161,8 @@ __device__ __forceinline__ void ctx_bind(Ctx &c, unsigned char *smem) {
     c.sr = reinterpret_cast<float *>(c.sb + P.capacity);
     c.lim = reinterpret_cast<double *>(c.sr + P.capacity);   // capacity is a multiple of 64 -> 8-byte aligned
     c.rp = c.lim + 8;
-    c.nreq = reinterpret_cast<int *>(c.rp + 2);
+    c.phi = c.rp + 2;
+    c.nreq = reinterpret_cast<int *>(c.phi + 8);
     c.list = reinterpret_cast<uint16_t *>(c.nreq + 8);
 }
 
@@ -290,10 +291,10 @@ struct PathRef {
 
 __device__ __forceinline__ void prefetch_first_path(Ctx &c, int src, int dst) {
     const Params &P = c.P;
-    int path = G(P.pair_paths)[(src * P.n_nodes + dst) * P.k_paths];
+    int path = uniform_i32(G(P.pair_paths)[(src * P.n_nodes + dst) * P.k_paths]);
     c.pre_id = path;
     if (path >= 0) {
-        c.pre_hops = G(P.path_hops)[path];
+        c.pre_hops = uniform_i32(G(P.path_hops)[path]);
         c.pre_mylink = (c.lane < c.pre_hops) ? G(P.path_links)[path * P.max_hops + c.lane] : 0;
         c.pre_m0 = G(P.path_mask)[2 * path];
         c.pre_m1 = G(P.path_mask)[2 * path + 1];
@@ -406,32 +407,36 @@ __device__ __forceinline__ GnLin gn_eval(Ctx &c, const PathRef &p, int L, int s,
         int idx = c.list[j];
         uint32_t a = c.sa[idx], b = c.sb[idx];
         int sk = rec_slot<R32>(a, b), nk = rec_n<R32>(a, b), mk = rec_mod<R32>(a, b);
+        int adi = abs((2 * sk + nk) - c2);               // centre distance in half-slots (exact)
         uint64_t m0, m1;
         if (R32) { m0 = a & (uint32_t)p.m0; m1 = 0; }
         else { int pk = a & 0xFFFF; m0 = G(P.path_mask)[2 * pk] & p.m0; m1 = G(P.path_mask)[2 * pk + 1] & p.m1; }
-        double bk = P.slot_bw * nk;
-        int dfi = (2 * sk + nk) - c2;                      // centre distance in half-slots (exact)
-        double adf = (0.5 * P.slot_bw) * (double)abs(dfi); // |fc_k - fc|
-        double hi = adf + 0.5 * bk, lo = adf - 0.5 * bk;   // lo > 0: allocations never overlap
-        double corr = 0.0;
-        if (!UNIFORM_ALPHA || nk > P.tab_nmax) corr = P.mod_phi53[mk] * (bk / adf);
-        terms += __popcll((unsigned long long)m0) + __popcll((unsigned long long)m1);
         if (UNIFORM_ALPHA) {
-            double A;
-            int adi = abs(dfi);
+            double A, corr;
             if (nk <= P.tab_nmax) {   // (asinh difference, Bk/|df|) depend on two small integers only: one 16-byte gather
                 const auto *t = G(reinterpret_cast<const double *>(P.pair_tab)) + 2 * ((nk - 1) * P.tab_stride + adi);
                 A = t[0];
-                corr = P.mod_phi53[mk] * t[1];
+                corr = c.phi[mk] * t[1];
             } else {
-                double ck = P.alpha0_cl * bk;
-                A = asinh_diff(ck * hi, ck * lo);
+                double bk = P.slot_bw * nk, adf = (0.5 * P.slot_bw) * (double)adi, ck = P.alpha0_cl * bk;
+                A = asinh_diff(ck * (adf + 0.5 * bk), ck * (adf - 0.5 * bk));   // adf > bk/2: allocations never overlap
+                corr = c.phi[mk] * (bk / adf);
             }
             double w1 = 0.0, w2 = 0.0;
-            while (m0) { int l = __ffsll((unsigned long long)m0) - 1; m0 &= m0 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
-            while (m1) { int l = 64 + __ffsll((unsigned long long)m1) - 1; m1 &= m1 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
+            if (R32) {
+                uint32_t m = (uint32_t)m0;
+                terms += __popc(m);
+                while (m) { int l = __ffs(m) - 1; m &= m - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
+            } else {
+                terms += __popcll((unsigned long long)m0) + __popcll((unsigned long long)m1);
+                while (m0) { int l = __ffsll((unsigned long long)m0) - 1; m0 &= m0 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
+                while (m1) { int l = 64 + __ffsll((unsigned long long)m1) - 1; m1 &= m1 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
+            }
             part += A * w1 - corr * w2;
         } else {
+            double bk = P.slot_bw * nk, adf = (0.5 * P.slot_bw) * (double)adi;
+            double hi = adf + 0.5 * bk, lo = adf - 0.5 * bk, corr = c.phi[mk] * (bk / adf);
+            terms += __popcll((unsigned long long)m0) + __popcll((unsigned long long)m1);
             while (m0 | m1) {
                 int l;
                 if (m0) { l = __ffsll((unsigned long long)m0) - 1; m0 &= m0 - 1; }
@@ -500,7 +505,7 @@ __device__ __forceinline__ void policy_first_fit(Ctx &c, int src, int dst, doubl
         uint64_t runs = free_ext;   // run-AND of length r, extended modulation by modulation
         int r = 1, L = -1;
         for (int m = max_mod; m >= 0; m--) {
-            int n = c.nreq[m];
+            int n = uniform_i32(c.nreq[m]);
             if (n <= 0) continue;
             if (n + 1 < r) { runs = free_ext; r = 1; }   // slot counts normally grow as the modulation index falls
             runs = run_and(runs, r, n + 1);
@@ -575,7 +580,6 @@ __device__ __forceinline__ int evaluate_action(Ctx &c, int src, int dst, double 
 template <bool R32>
 __device__ __forceinline__ void release_due(Ctx &c, float now) {
     const Params &P = c.P;
-    if (!(c.min_rel <= now)) return;
     int nchunks = (c.active + kWave - 1) / kWave;
     for (int ch = nchunks - 1; ch >= 0; ch--) {
         int i = ch * kWave + c.lane;
@@ -600,14 +604,6 @@ __device__ __forceinline__ void release_due(Ctx &c, float now) {
             __syncthreads();
         }
     }
-    float mn = INFINITY;
-    for (int base = 0; base < c.active; base += kWave) {
-        int i = base + c.lane;
-        if (i < c.active) mn = fminf(mn, c.sr[i]);
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) mn = fminf(mn, __shfl_xor(mn, m));
-    c.min_rel = mn;
 }
 
 // ---- _next_service, request half (envs/qrmsa.pyx:1067-1111): draw/replay the next request, advance the clock ---
@@ -694,7 +690,7 @@ __device__ __forceinline__ void draw_next(Ctx &c) {
 __device__ __forceinline__ void reset_env(Ctx &c) {
     const Params &P = c.P;
     DevEnv *e = c.e;
-    c.active = 0; c.min_rel = INFINITY;
+    c.active = 0;
     int words = P.n_links * P.row_words;
     for (int i = c.lane; i < words; i += kWave) c.occ[i] = word_range(i % P.row_words, 0, P.n_slots);
     if (c.lane == 0) {
@@ -802,9 +798,7 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
         if (rec) *rec = r;
     }
     if (outcome == 0) {
-        rel = uniform_f32(rel);
         c.active++;
-        c.min_rel = fminf(c.min_rel, rel);
     }
     __syncthreads();
     draw_next(c);                                 // first half of _next_service (:1079-1111)
@@ -838,11 +832,11 @@ __device__ __forceinline__ void load_state(Ctx &c) {
     c.br_reg = (c.lane < P.n_bit_rates && P.n_bit_rates <= kWave) ? (float)P.bit_rates[c.lane] : 0.f;
     __syncthreads();
     c.active = c.e->st.active;
-    c.min_rel = c.e->min_rel;
     c.pre_id = -1;
     if (c.e->have_request) prefetch_first_path(c, c.e->cur_src, c.e->cur_dst);
     // per-replica acceptance limits in the linear domain (see qot_ok)
     if (c.lane < P.n_mods) c.lim[c.lane] = pow(10.0, -(P.mod_thr[c.lane] + c.e->margin) / 10.0);
+    if (c.lane < kMaxMods) c.phi[c.lane] = c.lane < P.n_mods ? P.mod_phi53[c.lane] : 0.0;
     if (c.lane == 0) { c.rp[0] = 1.0 / c.e->launch_power; c.rp[1] = c.e->launch_power * c.e->launch_power; }
     // slots needed by the current request (kept in LDS between requests, recomputed on load)
     if (c.lane < P.n_mods)
@@ -859,7 +853,6 @@ __device__ __forceinline__ void store_state(Ctx &c) {
     for (int m = 32; m >= 1; m >>= 1) terms += __shfl_xor(terms, m);
     if (c.lane == 0) {
         c.e->st.active = c.active;
-        c.e->min_rel = c.min_rel;
         c.e->st.total_gn_evals += c.gn_evals;
         c.e->st.total_gn_shortcuts += c.gn_skips;
         c.e->st.total_interferer_terms += terms;
