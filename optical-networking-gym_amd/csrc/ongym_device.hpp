@@ -96,8 +96,8 @@ struct Params {
 //   occ u64[E*W] | lw1 f64[E] | lw2 f64[E] | lcl f64[E] | lsc f64[E] | DevEnv | sa u32[C] | sb u32[C] | sr f32[C] |
 //   lim f64[8] | rp f64[2] | phi f64[8] | nreq i32[8] | list u16[C]
 // ---------------------------------------------------------------------------------------------------------------
-__host__ __device__ inline size_t lds_bytes(int n_links, int row_words, int capacity) {
-    size_t b = (size_t)n_links * row_words * 8 + (size_t)n_links * 32 + ((sizeof(DevEnv) + 7) & ~(size_t)7);
+__host__ __device__ inline size_t lds_bytes(int n_links, int row_words, int capacity, int uniform_alpha) {
+    size_t b = (size_t)n_links * row_words * 8 + (size_t)n_links * (uniform_alpha ? 16 : 32) + ((sizeof(DevEnv) + 7) & ~(size_t)7);
     b += (size_t)capacity * 12 + 64 + 16 + 64 + 32 + (size_t)capacity * 2;
     return (b + 15) & ~(size_t)15;
 }
@@ -153,9 +153,10 @@ __device__ __forceinline__ void ctx_bind(Ctx &c, unsigned char *smem) {
     c.occ = reinterpret_cast<uint64_t *>(smem);
     c.lw1 = reinterpret_cast<double *>(c.occ + (size_t)P.n_links * P.row_words);
     c.lw2 = c.lw1 + P.n_links;
+    // the per-link alpha tables exist only when the attenuation is not uniform
     c.lcl = c.lw2 + P.n_links;
-    c.lsc = c.lcl + P.n_links;
-    c.e = reinterpret_cast<DevEnv *>(c.lsc + P.n_links);
+    c.lsc = c.lcl + (P.uniform_alpha ? 0 : P.n_links);
+    c.e = reinterpret_cast<DevEnv *>(c.lsc + (P.uniform_alpha ? 0 : P.n_links));
     c.sa = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(c.e) + ((sizeof(DevEnv) + 7) & ~(size_t)7));
     c.sb = c.sa + P.capacity;
     c.sr = reinterpret_cast<float *>(c.sb + P.capacity);
@@ -821,7 +822,8 @@ __device__ __forceinline__ void load_state(Ctx &c) {
     uint64_t *le = reinterpret_cast<uint64_t *>(c.e);
     for (int i = c.lane; i < (int)(sizeof(DevEnv) / 8); i += kWave) le[i] = ge[i];
     for (int i = c.lane; i < P.n_links; i += kWave) {
-        c.lw1[i] = P.link_w1[i]; c.lw2[i] = P.link_w2[i]; c.lcl[i] = P.link_cl[i]; c.lsc[i] = P.link_selfc[i];
+        c.lw1[i] = P.link_w1[i]; c.lw2[i] = P.link_w2[i];
+        if (!P.uniform_alpha) { c.lcl[i] = P.link_cl[i]; c.lsc[i] = P.link_selfc[i]; }
     }
     int words = P.n_links * P.row_words;
     const uint64_t *g = P.occ + (size_t)c.replica * words;

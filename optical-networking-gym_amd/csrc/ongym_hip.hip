@@ -16,8 +16,10 @@ using namespace ongym;
 // ---------------------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------------------
-template <bool UA, bool R32>
-__global__ __launch_bounds__(64, 4) void k_run(const Params *__restrict__ Pp, int mode, int nsteps, const int32_t *actions, int32_t *act_out,
+// WAVES = waves per SIMD the register allocation is bounded for: 5 when the replica's LDS block is <= 8 KiB (20 replicas
+// per CU), else 4
+template <bool UA, bool R32, int WAVES>
+__global__ __launch_bounds__(64, WAVES) void k_run(const Params *__restrict__ Pp, int mode, int nsteps, const int32_t *actions, int32_t *act_out,
                                             uint8_t *flag_out, ongym_step_rec *out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const Params &P = *Pp;
@@ -446,12 +448,12 @@ static int build(ongym_env *env, const ongym_config *c) {
         for (size_t i = 0; i < all.size(); i++) all[i] = row[i % P.row_words];
         HIP_TRY(env, hipMemcpy(P.occ, all.data(), all.size() * 8, hipMemcpyHostToDevice));
     }
-    env->lds = lds_bytes(E, P.row_words, c->capacity);
+    env->lds = lds_bytes(E, P.row_words, c->capacity, P.uniform_alpha);
     if (env->lds > 64 * 1024) {
         if (env->lds > 160 * 1024) return fail_arg(env, "state does not fit the 160 KiB LDS: lower capacity", ONGYM_E_LIMIT);
 #define ONGYM_SET_LDS(K) HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->lds))
-        ONGYM_SET_LDS((k_run<true, true>)); ONGYM_SET_LDS((k_run<true, false>));
-        ONGYM_SET_LDS((k_run<false, true>)); ONGYM_SET_LDS((k_run<false, false>));
+        ONGYM_SET_LDS((k_run<true, true, 4>)); ONGYM_SET_LDS((k_run<true, false, 4>));
+        ONGYM_SET_LDS((k_run<false, true, 4>)); ONGYM_SET_LDS((k_run<false, false, 4>));
         ONGYM_SET_LDS((k_query<true, true>)); ONGYM_SET_LDS((k_query<true, false>));
         ONGYM_SET_LDS((k_query<false, true>)); ONGYM_SET_LDS((k_query<false, false>));
         ONGYM_SET_LDS(k_reset);
@@ -614,8 +616,14 @@ static int launch_run(ongym_env *env, int mode, int nsteps, const int32_t *d_act
     HIP_TRY(env, hipEventRecord(env->ev0, env->stream));
     const dim3 grid(env->P.batch), block(64);
 #define ONGYM_LAUNCH_RUN(UA, R)                                                                                    \
-    hipLaunchKernelGGL((k_run<UA, R>), grid, block, env->lds, env->stream, env->d_P, mode, nsteps, d_actions,       \
-                       d_act_out, d_flag_out, d_out)
+    do {                                                                                                           \
+        if (env->lds <= 8192)                                                                                      \
+            hipLaunchKernelGGL((k_run<UA, R, 5>), grid, block, env->lds, env->stream, env->d_P, mode, nsteps,       \
+                               d_actions, d_act_out, d_flag_out, d_out);                                           \
+        else                                                                                                       \
+            hipLaunchKernelGGL((k_run<UA, R, 4>), grid, block, env->lds, env->stream, env->d_P, mode, nsteps,       \
+                               d_actions, d_act_out, d_flag_out, d_out);                                           \
+    } while (0)
     if (env->P.uniform_alpha) { if (env->P.rec32) ONGYM_LAUNCH_RUN(true, true); else ONGYM_LAUNCH_RUN(true, false); }
     else { if (env->P.rec32) ONGYM_LAUNCH_RUN(false, true); else ONGYM_LAUNCH_RUN(false, false); }
 #undef ONGYM_LAUNCH_RUN

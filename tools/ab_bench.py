@@ -18,7 +18,7 @@ import bench
 from optical_networking_gym.envs.batched import BatchedQRMSAEnv
 wl = bench.WORKLOADS[%(workload)r]
 env = BatchedQRMSAEnv(tables=bench.build_tables(wl["topology"]), modulations=bench.jocn_modulations(),
-                      batch_size=%(batch)d, num_spectrum_resources=wl["S"], capacity=wl["capacity"], episode_length=1000,
+                      batch_size=%(batch)d, num_spectrum_resources=wl["S"], capacity=%(capacity)d or wl["capacity"], episode_length=1000,
                       auto_reset=True, load=wl["load"], bit_rate_selection="discrete", bit_rates=wl["bit_rates"])
 env.seed(1); env.reset()
 env.step_policy(%(warm)d, record=False); env.sync()
@@ -37,13 +37,14 @@ ap.add_argument("--batch", type=int, default=65536)
 ap.add_argument("--steps", type=int, default=250)
 ap.add_argument("--warm", type=int, default=500)
 ap.add_argument("--workload", default="nsfnet320")
+ap.add_argument("--capacity", type=int, default=0)
 a = ap.parse_args()
 res = {l: [] for l in a.libs}
 check = {}
 for rd in range(a.rounds):
     for lib in a.libs:
         env = dict(os.environ, ONGYM_HIP_LIB=os.path.abspath(lib))
-        code = CHILD % dict(repo=REPO, workload=a.workload, batch=a.batch, warm=a.warm, reps=a.reps, steps=a.steps)
+        code = CHILD % dict(repo=REPO, workload=a.workload, batch=a.batch, warm=a.warm, reps=a.reps, steps=a.steps, capacity=a.capacity)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
         if out.returncode:
             print(lib, "FAILED", out.stderr[-800:]); continue
