@@ -90,7 +90,7 @@ def cpu_baseline(tables, wl, seconds_target=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--steps", type=int, default=10000)
     ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--batch", type=int, default=65536, help="replicas per GPU")
     ap.add_argument("--workload", default="nsfnet320", choices=sorted(WORKLOADS))
@@ -186,7 +186,7 @@ def main():
                        "steps_per_launch": args.steps_per_launch, "parallelism": f"replica-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_run<true>", "avg_launch_ms": avg_launch_s * 1e3,
+                         "kernel": "k_run<uniform_alpha,rec32,waves> (csrc/ongym_hip.hip)", "avg_launch_ms": avg_launch_s * 1e3,
                          "algorithmic_bytes_per_env_step": bytes_step, "env_steps_per_launch": steps_per_launch_total,
                          **counters},
             "blocking_rate": 1.0 - stats_sum["total_accepted"] / stats_sum["total_steps"],
