@@ -95,6 +95,9 @@ typedef struct ongym_config {
     const double *replica_launch_power_w; /* [batch] */
     const double *replica_load;           /* [batch] */
     const double *replica_margin;         /* [batch] */
+    /* observation() only (qrmsa.pyx:583-781): route lengths normalised by the min/max LINK length (:692-705) */
+    const double *path_len_norm;          /* [n_paths] or NULL (ongym_observe then fails) */
+    double max_bit_rate;                  /* max(bit_rates), qrmsa.pyx:679 */
 } ongym_config;
 
 /* One service request; replaces the fields drawn in QRMSAEnv._next_service (qrmsa.pyx:1079-1101). */
@@ -181,6 +184,13 @@ int ongym_step_policy(ongym_env *env, int32_t policy, int32_t nsteps, ongym_step
 int ongym_step_actions(ongym_env *env, const int32_t *actions, ongym_step_rec *out);
 /* The heuristic alone, without stepping: actions[batch], flags[batch] (ONGYM_F_BLOCKED_*) (heuristics.py:923-966). */
 int ongym_policy_actions(ongym_env *env, int32_t policy, int32_t *actions, uint8_t *flags);
+
+/* QRMSAEnv.observation() (qrmsa.pyx:583-781, gen_observation=True) for the CURRENT request of every replica:
+ * obs  float32 [batch][1 + 2 + k_paths + k_paths*n_mods*12]  (bit rate, src, dst, k route lengths, 12 features per
+ *      (path, modulation) pair incl. the normalised GSNR of calculate_osnr_observation, core/osnr.pyx:259-369)
+ * mask uint8   [batch][k_paths*n_mods*n_slots + 1]            (info['mask'], last entry = reject = 1)
+ * Needs uniform attenuation, n_mods == modulations_to_consider and slot_bandwidth == channel_width*1e9. */
+int ongym_observe(ongym_env *env, float *obs, uint8_t *mask);
 
 /* Plugin-API queries on one replica (host buffers always): */
 /* QRMSAEnv.get_available_slots(path) (qrmsa.pyx:1482-1512): out[n_slots], 1 = free on every link of the path */

@@ -77,6 +77,8 @@ struct Params {
                                     //  half slots), uniform alpha only; NULL = always compute
     int tab_nmax, tab_stride;
     const double *bit_rates, *bit_rate_cum, *node_cum;
+    const double *path_len_norm;    // [P] observation(): (length - min link) / (max link - min link)
+    double max_bit_rate;
     int mod_se[kMaxMods];
     double mod_thr[kMaxMods];
     double mod_phi53[kMaxMods];     // Phi_mod[se-1] * 5/3  (core/osnr.pyx:38-41,86-92)
@@ -813,6 +815,201 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
     }
     c.active_sum += c.active;
     if (terminated && P.auto_reset) { __syncthreads(); reset_env(c); }
+}
+
+
+// ---- observation() + action mask (envs/qrmsa.pyx:583-781; calculate_osnr_observation core/osnr.pyx:259-369) -----------
+// For one path the interferer part of the NLI sum of a candidate centred at half-slot x is
+//     F(x) = sum_k [ A(n_k, |x - c_k|) * w1_k - Phi_k * R(n_k, |x - c_k|) * w2_k ],
+// a superposition of per-interferer profiles that does not depend on the candidate's own width: F is built ONCE per
+// path over all 2S+1 centres (lanes over x -> the pair-table reads of one interferer are contiguous), then each of the
+// M x (valid starts) candidates costs one LDS read + the O(1) ASE/self terms + one log10.
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
+    return v;
+}
+
+template <bool R32>
+__device__ __forceinline__ void observe_env(Ctx &c, double *Fx, float *obs, uint8_t *mask) {
+    const Params &P = c.P;
+    const int K = P.k_paths, M = P.n_mods, S = P.n_slots, N = P.n_nodes;
+    const int nx = 2 * S + 1, W = P.row_words;
+    const int obs_dim = 3 + K + K * M * 12;
+    const long long nact = (long long)K * M * S + 1;
+    DevEnv *e = c.e;
+    if (!e->have_request) {
+        for (int i = c.lane; i < obs_dim; i += kWave) obs[i] = 0.f;
+        for (long long i = c.lane; i < nact; i += kWave) mask[i] = 0;
+        return;
+    }
+    const int src = e->cur_src, dst = e->cur_dst;
+    const double br = (double)e->cur_br;
+    if (c.lane == 0) {
+        obs[0] = (float)(br / P.max_bit_rate);                       // :688
+        obs[1] = (float)((double)src / (double)(N - 1));             // :682-686
+        obs[2] = (float)((double)dst / (double)(N - 1));
+        mask[nact - 1] = 1;                                          // :766
+    }
+    for (int k = 0; k < K; k++) {
+        const int path = G(P.pair_paths)[(src * N + dst) * K + k];
+        float *frow = obs + 3 + K + k * M * 12;
+        uint8_t *mrow = mask + (long long)k * M * S;
+        if (c.lane == 0) obs[3 + k] = path >= 0 ? (float)P.path_len_norm[path] : 0.f;   // :701-705
+        if (path < 0) {
+            for (int i = c.lane; i < M * 12; i += kWave) frow[i] = -1.f;
+            for (int i = c.lane; i < M * S; i += kWave) mrow[i] = 0;
+            continue;
+        }
+        PathRef p = load_path(c, path);
+        const uint64_t free_ext = path_free_ext(c, p);
+        // ---- free slots on the path and its free blocks (:632-652): number of blocks, sum of squared lengths
+        const uint64_t aw = (c.lane == (S >> 6)) ? (free_ext & ~(1ull << (S & 63))) : free_ext;
+        const int tot = wave_sum_i32(c.lane < W ? __popcll((unsigned long long)aw) : 0);
+        int nb_l = 0, len2_l = 0, prev_zero = -1;
+        for (int i = 0; i < W; i++) {
+            const uint64_t w = readlane_u64(aw, i);
+            const uint64_t nxt = (i + 1 < W) ? (readlane_u64(aw, i + 1) & 1ull) : 0ull;
+            const uint64_t ends = w & ~((w >> 1) | (nxt << 63));      // last slot of every free block
+            if ((ends >> c.lane) & 1ull) {
+                uint64_t below = ~w & lanes_below(c.lane);
+                int pz = below ? (i * 64 + 63 - __clzll((unsigned long long)below)) : prev_zero;
+                int len = (i * 64 + c.lane) - pz;
+                nb_l += 1; len2_l += len * len;
+            }
+            if (~w) prev_zero = i * 64 + 63 - __clzll((unsigned long long)~w);
+        }
+        const int nb = wave_sum_i32(nb_l);
+        const double len2 = (double)wave_sum_i32(len2_l);
+        // ---- interferer field F(x)
+        const int L = gn_build_list<R32>(c, p.m0, p.m1);
+        for (int x = c.lane; x < nx + 1; x += kWave) Fx[x] = 0.0;
+        __syncthreads();
+        for (int base = 0; base < L; base += kWave) {
+            const int j = base + c.lane;
+            int c2k = 0, nk = 0;
+            double w1 = 0.0, pw2 = 0.0;
+            if (j < L) {
+                const int idx = c.list[j];
+                const uint32_t a = c.sa[idx], b = c.sb[idx];
+                const int sk = rec_slot<R32>(a, b);
+                nk = rec_n<R32>(a, b);
+                c2k = 2 * sk + nk;
+                uint64_t m0, m1;
+                if (R32) { m0 = a & (uint32_t)p.m0; m1 = 0; }
+                else { int pk = a & 0xFFFF; m0 = G(P.path_mask)[2 * pk] & p.m0; m1 = G(P.path_mask)[2 * pk + 1] & p.m1; }
+                double w2 = 0.0;
+                while (m0) { int l = __ffsll((unsigned long long)m0) - 1; m0 &= m0 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
+                while (m1) { int l = 64 + __ffsll((unsigned long long)m1) - 1; m1 &= m1 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
+                pw2 = c.phi[rec_mod<R32>(a, b)] * w2;
+            }
+            const int tile_n = min(kWave, L - base);
+            for (int x0 = 0; x0 < nx; x0 += kWave) {
+                const int x = x0 + c.lane;
+                double f = 0.0;
+                for (int t = 0; t < tile_n; t++) {
+                    const int cc = __builtin_amdgcn_readlane(c2k, t), nn = __builtin_amdgcn_readlane(nk, t);
+                    const double w1t = readlane_f64(w1, t), pw2t = readlane_f64(pw2, t);
+                    const int adi = abs(x - cc);
+                    if (adi > nn) {   // |df| > Bk/2; positions overlapping the interferer are never valid starts
+                        double A, R;
+                        if (nn <= P.tab_nmax) {
+                            const auto *tb = G(reinterpret_cast<const double *>(P.pair_tab)) + 2 * ((nn - 1) * P.tab_stride + adi);
+                            A = tb[0]; R = tb[1];
+                        } else {
+                            double bk = P.slot_bw * nn, adf = (0.5 * P.slot_bw) * (double)adi, ck = P.alpha0_cl * bk;
+                            A = asinh_diff(ck * (adf + 0.5 * bk), ck * (adf - 0.5 * bk));
+                            R = bk / adf;
+                        }
+                        f += A * w1t - R * pw2t;
+                    }
+                }
+                if (x < nx) Fx[x] += f;
+            }
+        }
+        __syncthreads();
+        // ---- per modulation, best first (mod_list = reversed(modulations[0:M]), :716-717)
+        uint64_t runs = free_ext;
+        int r = 1;
+        const double pw1 = G(P.path_w1)[path], pase = G(P.path_ase)[path];
+        for (int mi = 0; mi < M; mi++) {
+            const int m = M - 1 - mi;
+            const int n = uniform_i32(c.nreq[m]);
+            float *f12 = frow + mi * 12;
+            uint8_t *mm = mrow + (long long)mi * S;
+            if (n <= 0 || n > S) {
+                if (c.lane == 0) for (int q = 0; q < 12; q++) f12[q] = (q == 4 || q == 10) ? (float)(2.0 * ((double)tot / S - 0.5)) : 0.f;
+                for (int i = c.lane; i < S; i += kWave) mm[i] = 0;
+                continue;
+            }
+            if (n + 1 < r) { runs = free_ext; r = 1; }
+            runs = run_and(runs, r, n + 1);                              // valid starts of _get_candidates (:590)
+            const double thr = P.mod_thr[m], bw = P.slot_bw * n;
+            const double self = pw1 * G(P.self_asinh)[n], nlic = G(P.nli_coef)[n] * c.rp[1];
+            int cnt_l = 0, sum_l = 0, sum2_l = 0, max_l = 0;
+            double os_l = 0.0, os2_l = 0.0, omax_l = -1e300;
+            for (int i = 0; i < W; i++) {
+                const uint64_t w = readlane_u64(runs, i);
+                const int s = i * 64 + c.lane;
+                const bool valid = ((w >> c.lane) & 1ull) && s < S;
+                uint8_t bit = 0;
+                if (valid) {
+                    cnt_l += 1; sum_l += s; sum2_l += s * s; max_l = max(max_l, s);
+                    const double fc = P.f0 + (P.slot_bw * s) + (P.slot_bw * (n / 2.0));
+                    const double acc = (bw * fc * pase) * c.rp[0] + nlic * (self + Fx[2 * s + n]);
+                    const double gsnr = -10.0 * log10(acc);
+                    const double nv = rint(((gsnr - thr) / fabs(thr)) * 1e10) / 1e10;   // np.round(x, 10), osnr.pyx:368
+                    os_l += nv; os2_l += nv * nv; omax_l = fmax(omax_l, nv);
+                    bit = nv >= 0.0 ? 1 : 0;                                             // :759-763
+                }
+                if (s < S) mm[s] = bit;
+            }
+            const int cnt = wave_sum_i32(cnt_l);
+            const double ssum = (double)wave_sum_i32(sum_l), ssum2 = (double)wave_sum_i32(sum2_l);
+            const int smax = wave_max_i32(max_l);
+            const double osum = wave_sum(os_l), osum2 = wave_sum(os2_l), omax = wave_max_f64(omax_l);
+            if (c.lane == 0) {
+                const double Sd = (double)S, S1 = (double)(S - 1);
+                double mean_s = 0.0, std_s = 0.0, om = 0.0, ov = 0.0, best = 0.0;
+                if (cnt > 0) {
+                    mean_s = ssum / cnt;
+                    std_s = sqrt(fmax(ssum2 / cnt - mean_s * mean_s, 0.0));
+                    om = osum / cnt;
+                    ov = fmax(osum2 / cnt - om * om, 0.0);
+                    best = fmax(omax, 0.0);                              // osnr_best starts at 0.0 (:604,622)
+                }
+                double mb = 0.0, sb = 0.0;
+                if (nb > 0) {
+                    double bm = (double)tot / nb;
+                    mb = ((bm - 4.0) / 4.0) / 100.0;                     // :646-648
+                    sb = sqrt(fmax(len2 / nb - bm * bm, 0.0)) / 100.0;
+                }
+                const double adj = ((double)n - 5.5) / 3.5;
+                f12[0] = (float)((double)cnt / Sd);
+                f12[1] = (float)(mean_s / S1);
+                f12[2] = (float)(std_s / S1);
+                f12[3] = (float)(adj > 0.0 ? adj : 0.0);
+                f12[4] = (float)(2.0 * ((double)tot - 0.5 * Sd) / Sd);
+                f12[5] = (float)mb;
+                f12[6] = (float)sb;
+                f12[7] = (float)best;
+                f12[8] = (float)om;
+                f12[9] = (float)ov;
+                f12[10] = (float)(2.0 * (((double)tot / Sd) - 0.5));
+                f12[11] = (float)((double)smax / S1);
+            }
+        }
+    }
 }
 
 __device__ __forceinline__ void load_state(Ctx &c) {

@@ -94,6 +94,25 @@ __global__ __launch_bounds__(64) void k_reset(const Params *__restrict__ Pp, con
     store_state(c);
 }
 
+template <bool R32>
+__global__ __launch_bounds__(64) void k_observe(const Params *__restrict__ Pp, float *obs, uint8_t *mask) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const Params &P = *Pp;
+    Ctx c(P);
+    c.lane = threadIdx.x;
+    c.replica = blockIdx.x;
+    c.lane_terms = 0;
+    c.gn_evals = 0;
+    c.gn_skips = 0;
+    c.paths_tried = 0; c.path_hops = 0; c.active_sum = 0;
+    ctx_bind(c, smem);
+    load_state(c);
+    double *Fx = reinterpret_cast<double *>(smem + lds_bytes(P.n_links, P.row_words, P.capacity, P.uniform_alpha));
+    const size_t obs_dim = 3 + P.k_paths + (size_t)P.k_paths * P.n_mods * 12;
+    const size_t nact = (size_t)P.k_paths * P.n_mods * P.n_slots + 1;
+    observe_env<R32>(c, Fx, obs + (size_t)c.replica * obs_dim, mask + (size_t)c.replica * nact);
+}
+
 __global__ void k_seed(Params P, uint64_t seed) {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= P.batch) return;
@@ -197,6 +216,7 @@ struct ongym_env {
     void *d_trace = nullptr;        // owned copy of a host trace
     ongym_step_rec *d_out = nullptr; size_t d_out_n = 0;
     int32_t *d_actions = nullptr; int32_t *d_act_out = nullptr; uint8_t *d_flag_out = nullptr; uint8_t *d_mask = nullptr;
+    float *d_obs = nullptr; uint8_t *d_obsmask = nullptr;   // lazily allocated staging for ongym_observe with host buffers
     int32_t *d_scratch_i = nullptr; size_t scratch_i_bytes = 0; double *d_scratch_d = nullptr;
     bool has_source = false;
 };
@@ -285,6 +305,8 @@ static int build(ongym_env *env, const ongym_config *c) {
     P.req_mode = kReqNone;
     P.f0 = c->frequency_start; P.slot_bw = c->slot_bandwidth; P.channel_width = c->channel_width;
     P.mean_holding = c->mean_holding_time;
+    P.max_bit_rate = c->max_bit_rate;
+    P.path_len_norm = nullptr;
     P.mean_holding_f = (float)c->mean_holding_time;
 
     // derived GN tables in fp64 (core/osnr.pyx:22-24, 52-55, 58-61, 109-125)
@@ -415,6 +437,7 @@ static int build(ongym_env *env, const ongym_config *c) {
     if ((rc = upload(env, c->bit_rate_mode == 0 ? c->bit_rate_cum : &one, c->bit_rate_mode == 0 ? (size_t)c->n_bit_rates : 1, &P.bit_rate_cum))) return rc;
     if (c->bit_rate_mode != 0) P.n_bit_rates = 1;
     if ((rc = upload(env, c->node_cum, (size_t)N, &P.node_cum))) return rc;
+    if (c->path_len_norm && (rc = upload(env, c->path_len_norm, (size_t)NP, &P.path_len_norm))) return rc;
 
     // mutable state
     const size_t B = (size_t)c->batch;
@@ -672,6 +695,45 @@ int ongym_step_actions(ongym_env *env, const int32_t *actions, ongym_step_rec *o
         HIP_TRY(env, hipMemcpyAsync(out, env->d_out, (size_t)env->P.batch * sizeof(ongym_step_rec), hipMemcpyDeviceToHost, env->stream));
     } else if ((rc = launch_run(env, kModeActionStep, 1, env->d_actions, nullptr, nullptr, nullptr))) return rc;
     HIP_TRY(env, hipStreamSynchronize(env->stream));
+    return ONGYM_OK;
+}
+
+int ongym_observe(ongym_env *env, float *obs, uint8_t *mask) {
+    if (!env || !obs || !mask) return env ? fail_arg(env, "null obs/mask") : ONGYM_E_ARG;
+    const Params &P = env->P;
+    if (!P.path_len_norm || !(P.max_bit_rate > 0)) return fail_arg(env, "observation needs path_len_norm and max_bit_rate (discrete bit rates)");
+    if (!P.uniform_alpha) return fail_arg(env, "observation kernel needs uniform attenuation", ONGYM_E_LIMIT);
+    if (std::fabs(P.slot_bw - P.channel_width * 1e9) > 1e-6 * P.slot_bw) return fail_arg(env, "observation needs slot_bandwidth == channel_width*1e9");
+    HIP_TRY(env, hipSetDevice(env->cfg.device));
+    const size_t obs_dim = 3 + P.k_paths + (size_t)P.k_paths * P.n_mods * 12;
+    const size_t nact = (size_t)P.k_paths * P.n_mods * P.n_slots + 1;
+    const size_t B = (size_t)P.batch;
+    const size_t lds = env->lds + ((size_t)2 * P.n_slots + 2) * sizeof(double);
+    if (lds > 64 * 1024) {
+        HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_observe<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_observe<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    float *d_obs = obs; uint8_t *d_mask = mask;
+    if (!env->cfg.io_device) {
+        if (!env->d_obs) {
+            HIP_TRY(env, hipMalloc(reinterpret_cast<void **>(&env->d_obs), B * obs_dim * sizeof(float)));
+            env->allocs.push_back(env->d_obs);
+            HIP_TRY(env, hipMalloc(reinterpret_cast<void **>(&env->d_obsmask), B * nact));
+            env->allocs.push_back(env->d_obsmask);
+        }
+        d_obs = env->d_obs; d_mask = env->d_obsmask;
+    }
+    HIP_TRY(env, hipEventRecord(env->ev0, env->stream));
+    if (P.rec32) hipLaunchKernelGGL(k_observe<true>, dim3(P.batch), dim3(64), lds, env->stream, env->d_P, d_obs, d_mask);
+    else hipLaunchKernelGGL(k_observe<false>, dim3(P.batch), dim3(64), lds, env->stream, env->d_P, d_obs, d_mask);
+    HIP_TRY(env, hipGetLastError());
+    HIP_TRY(env, hipEventRecord(env->ev1, env->stream));
+    env->timed = true;
+    if (!env->cfg.io_device) {
+        HIP_TRY(env, hipMemcpyAsync(obs, d_obs, B * obs_dim * sizeof(float), hipMemcpyDeviceToHost, env->stream));
+        HIP_TRY(env, hipMemcpyAsync(mask, d_mask, B * nact, hipMemcpyDeviceToHost, env->stream));
+        HIP_TRY(env, hipStreamSynchronize(env->stream));
+    }
     return ONGYM_OK;
 }
 

@@ -39,6 +39,7 @@ class OngymConfig(C.Structure):
         ("mod_se", _i32p), ("mod_min_osnr", _f64p), ("bit_rates", _f64p), ("bit_rate_cum", _f64p),
         ("node_cum", _f64p),
         ("replica_launch_power_w", _f64p), ("replica_load", _f64p), ("replica_margin", _f64p),
+        ("path_len_norm", _f64p), ("max_bit_rate", C.c_double),
     ]
 
 
@@ -140,6 +141,10 @@ class ConfigHolder:
             c.replica_load = f64("rload", replica_load)
         if replica_margin is not None:
             c.replica_margin = f64("rmargin", replica_margin)
+        # observation(): route lengths normalised by min/max LINK length (qrmsa.pyx:692-705), max(bit_rates) (:679)
+        lo, hi = float(np.min(t.link_length)), float(np.max(t.link_length))
+        c.path_len_norm = f64("path_len_norm", [(x - lo) / (hi - lo) if hi != lo else 0.0 for x in t.path_length])
+        c.max_bit_rate = float(np.max(rates)) if bit_rate_selection == "discrete" else 0.0
         for name in ("rlp", "rload", "rmargin"):
             if name in keep and len(keep[name]) != batch:
                 raise ValueError("per-replica override arrays must have `batch` entries")
@@ -166,6 +171,7 @@ def _declare(lib):
     lib.ongym_step_policy.argtypes = [vp, C.c_int32, C.c_int32, vp]
     lib.ongym_step_actions.argtypes = [vp, vp, vp]
     lib.ongym_policy_actions.argtypes = [vp, C.c_int32, vp, vp]
+    lib.ongym_observe.argtypes = [vp, vp, vp]
     lib.ongym_query_available.argtypes = [vp, C.c_int32, C.c_int32, vp]
     lib.ongym_query_gsnr.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]
     lib.ongym_query_grid.argtypes = [vp, C.c_int32, vp]
@@ -182,15 +188,15 @@ def _declare(lib):
     lib.ongym_abi_version.argtypes = []
     lib.ongym_sizeof.argtypes = [C.c_int32]
     for name in ("ongym_create", "ongym_seed", "ongym_set_requests", "ongym_reset", "ongym_step_policy",
-                 "ongym_step_actions", "ongym_policy_actions", "ongym_query_available", "ongym_query_gsnr",
+                 "ongym_step_actions", "ongym_policy_actions", "ongym_observe", "ongym_query_available", "ongym_query_gsnr",
                  "ongym_query_grid", "ongym_query_services", "ongym_query_request", "ongym_stats_get", "ongym_sync",
-                 "ongym_abi_version", "ongym_sizeof", "ongym_query_candidates", "ongym_query_path_free"):
+                 "ongym_abi_version", "ongym_sizeof", "ongym_query_candidates", "ongym_query_path_free", "ongym_observe"):
         getattr(lib, name).restype = C.c_int32
 
 
 EXPORTED_SYMBOLS = (
     "ongym_create", "ongym_destroy", "ongym_seed", "ongym_set_requests", "ongym_reset", "ongym_step_policy",
-    "ongym_step_actions", "ongym_policy_actions", "ongym_query_available", "ongym_query_gsnr", "ongym_query_grid",
+    "ongym_step_actions", "ongym_policy_actions", "ongym_observe", "ongym_query_available", "ongym_query_gsnr", "ongym_query_grid",
     "ongym_query_services", "ongym_query_request", "ongym_query_candidates", "ongym_query_path_free",
     "ongym_stats_get", "ongym_sync", "ongym_last_kernel_ms",
     "ongym_last_error", "ongym_abi_version", "ongym_sizeof")

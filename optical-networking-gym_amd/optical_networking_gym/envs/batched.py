@@ -122,6 +122,14 @@ class BatchedQRMSAEnv:
                     "ongym_policy_actions")
         return actions, flags
 
+    def observe(self):
+        """observation() + action mask of every replica's current request: (float32 [B, obs_dim], uint8 [B, n_actions])."""
+        c = self.holder.struct
+        obs = np.zeros((self.batch_size, 3 + c.k_paths + c.k_paths * c.n_mods * 12), np.float32)
+        mask = np.zeros((self.batch_size, c.k_paths * c.n_mods * c.n_slots + 1), np.uint8)
+        self._check(self.lib.ongym_observe(self._h, obs.ctypes.data, mask.ctypes.data), "ongym_observe")
+        return obs, mask
+
     # ---- queries (plugin API) ----------------------------------------------------------------------------------------
     def available_slots(self, replica: int, path_id: int) -> np.ndarray:
         out = np.zeros(self.holder.struct.n_slots, np.int32)

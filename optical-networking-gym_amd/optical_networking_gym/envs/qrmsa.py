@@ -10,8 +10,8 @@ this view does no slot-grid or GN arithmetic of its own, it only converts betwee
 (`Service`, `Path`, graph attributes) and device records. It is the slow drop-in path for existing agents and plugin
 heuristics; batch-scale use goes through `envs.batched.BatchedQRMSAEnv`.
 
-Not covered yet (raise NotImplementedError rather than silently differ): `gen_observation=True` (observation + action
-mask), `measure_disruptions`, `defragmentation`, `bands` (quirk Q9), per-service CSV (`file_name`).
+`gen_observation=True` returns the device-computed observation vector and action mask (`ongym_observe`).
+Not covered yet (raise NotImplementedError rather than silently differ): `measure_disruptions`, `defragmentation`, `bands` (quirk Q9), per-service CSV (`file_name`).
 """
 from __future__ import annotations
 
@@ -90,9 +90,10 @@ class QRMSAEnv:
                  defragmentation: bool = False, n_defrag_services: int = 0, gen_observation: bool = True,
                  bands: object = None, device: int = 0, capacity: int = 1024, sync_views: bool = True,
                  requests: Optional[np.ndarray] = None):
-        if gen_observation:
-            raise NotImplementedError("gen_observation=True (observation + action mask) is not built yet: "
-                                      "pass gen_observation=False as the JOCN benchmark does")
+        self.gen_observation = bool(gen_observation)
+        if gen_observation and (bit_rate_selection != "discrete" or modulations_to_consider < len(topology.graph.get("modulations", []))):
+            raise NotImplementedError("gen_observation=True needs discrete bit rates and modulations_to_consider == "
+                                      "len(modulations) (the reference's observation() reads max(bit_rates), qrmsa.pyx:679)")
         if measure_disruptions or defragmentation or bands or file_name:
             raise NotImplementedError("measure_disruptions / defragmentation / bands / file_name are not built yet")
         if seed is not None and not isinstance(seed, (int, np.integer)):
@@ -186,6 +187,9 @@ class QRMSAEnv:
 
     # ---- gym surface ---------------------------------------------------------------------------------------------------
     def _blank_observation(self):
+        if self.gen_observation:   # observation() + action mask of the CURRENT request, computed on device (qrmsa.pyx:583-781)
+            obs, mask = self._dev.observe()
+            return obs[0], {"mask": mask[0]}
         # gen_observation=False: zeros, including the reject slot of the mask (qrmsa.pyx:584-587)
         return (np.zeros(self.observation_space.shape, np.float32),
                 {"mask": np.zeros(self.action_space.n, np.uint8)})
@@ -204,7 +208,7 @@ class QRMSAEnv:
     def step(self, action: int):
         cur = self.current_service
         rec = self._dev.step(np.array([int(action)], np.int32))[0]
-        obs, mask = self._blank_observation()
+        obs, mask = (None, None) if (rec["flags"] & (nat.F_QOT_ERROR | nat.F_NO_REQUEST)) else self._blank_observation()
         if rec["flags"] & nat.F_QOT_ERROR:
             route, mod_idx, slot = self.encoded_decimal_to_array(int(action))
             modulation = self.modulations[mod_idx]

@@ -554,6 +554,118 @@ int orc_services(const orc_env *e, ongym_service *out) {
     return n;
 }
 
+
+/* ---- observation() + action mask (envs/qrmsa.pyx:583-781) and calculate_osnr_observation (core/osnr.pyx:259-369) ----
+ * gen_observation=True path. obs: float32[1 + 2 + k + k*M*12], mask: uint8[k*M*S + 1].
+ * path_len_norm[p] = (path length - min link length) / (max link length - min link length)  (:692-705, quirk Q10)
+ * max_bit_rate = max(bit_rates) (:679). Assumes n_mods == modulations_to_consider (max_modulation_idx stays M-1, :543-581). */
+static double osnr_observation(const orc_env *e, int path_id, double bw, double fc, double P, double gsnr_th) {
+    const double beta_2 = -21.3e-27, gamma = 1.3e-3, h_plank = 6.626e-34, pi = M_PI;
+    double acc_gsnr = 0.0;
+    int H = e->cfg.max_hops, hops = e->path_hops[path_id];
+    for (int h = 0; h < hops; h++) {
+        int l = e->path_links[path_id * H + h];
+        double alpha = e->link_alpha[l], L = e->link_span_km[l], nf = e->link_nf[l];
+        for (int sp = 0; sp < e->link_nspans[l]; sp++) {
+            double l_eff_a = 1.0 / (2.0 * alpha);
+            double l_eff = (1.0 - exp(-2.0 * alpha * L * 1e3)) / (2.0 * alpha);
+            double sum_phi = asinh(pi * pi * fabs(beta_2) * (bw * bw) / (4.0 * alpha));
+            for (int k = 0; k < e->run_cnt[l]; k++) {
+                const orc_service *r = &e->pool[e->run[(size_t)l * e->pool_cap + k]];
+                double rb = r->bandwidth, rf = r->center_frequency;
+                double phi = (asinh(pi * pi * fabs(beta_2) * l_eff_a * rb * (rf - fc + (rb / 2.0)))
+                              - asinh(pi * pi * fabs(beta_2) * l_eff_a * rb * (rf - fc - (rb / 2.0))))
+                             - (PHI_MOD[e->mod_se[r->mod] - 1] * (rb / fabs(rf - fc)) * (5.0 / 3.0) * (l_eff / (L * 1e3)));
+                sum_phi += phi;
+            }
+            double ratio = P / bw;
+            double power_nli_span = (ratio * ratio * ratio) * (8.0 / (27.0 * pi * fabs(beta_2))) * (gamma * gamma)
+                                    * l_eff * sum_phi * bw;
+            double power_ase = bw * h_plank * fc * (exp(2.0 * alpha * L * 1e3) - 1.0) * nf;
+            acc_gsnr += 1.0 / (P / (power_ase + power_nli_span));
+        }
+    }
+    double gsnr = 10.0 * log10(1.0 / acc_gsnr);
+    return nearbyint(((gsnr - gsnr_th) / fabs(gsnr_th)) * 1e10) / 1e10;   /* np.round(x, 10), core/osnr.pyx:368 */
+}
+
+void orc_observe(orc_env *e, const double *path_len_norm, double max_bit_rate, float *obs, uint8_t *mask) {
+    int S = e->cfg.n_slots, K = e->cfg.k_paths, M = e->cfg.n_mods, N = e->cfg.n_nodes;
+    int32_t *avail = e->scratch_avail;
+    int32_t *starts = (int32_t *)malloc(sizeof(int32_t) * (S + 1));
+    double *vals = (double *)malloc(sizeof(double) * (S + 1));
+    int o = 0;
+    obs[o++] = (float)(e->cur.bit_rate / max_bit_rate);                 /* :688 */
+    obs[o++] = (float)((double)e->cur.src / (N - 1));                    /* :682-686 */
+    obs[o++] = (float)((double)e->cur.dst / (N - 1));
+    for (int k = 0; k < K; k++) {
+        int p = e->pair_paths[(e->cur.src * N + e->cur.dst) * K + k];
+        obs[o++] = p >= 0 ? (float)path_len_norm[p] : 0.0f;
+    }
+    memset(mask, 0, (size_t)K * M * S + 1);
+    double Pw = e->launch_power;
+    for (int k = 0; k < K; k++) {
+        int p = e->pair_paths[(e->cur.src * N + e->cur.dst) * K + k];
+        for (int mi = 0; mi < M; mi++) {
+            float *f = &obs[o]; o += 12;
+            for (int j = 0; j < 12; j++) f[j] = -1.0f;
+            if (p < 0) continue;
+            int m = M - 1 - mi;                                          /* mod_list = reversed(modulations[0:M]) :716-717 */
+            int n = orc_number_slots(e, e->cur.bit_rate, m);
+            orc_available(e, p, avail);
+            int cnt = orc_candidates(avail, S, n, starts, S + 1);
+            double mean_s = 0, std_s = 0, max_s = 0;
+            if (cnt > 0) {
+                for (int i = 0; i < cnt; i++) { mean_s += starts[i]; if (starts[i] > max_s) max_s = starts[i]; }
+                mean_s /= cnt;
+                for (int i = 0; i < cnt; i++) std_s += (starts[i] - mean_s) * (starts[i] - mean_s);
+                std_s = sqrt(std_s / cnt);
+            }
+            double best = 0.0, om = 0.0, ov = 0.0;
+            double bw = n * e->cfg.channel_width * 1e9;
+            for (int i = 0; i < cnt; i++) {
+                double fc = e->cfg.frequency_start + (e->cfg.channel_width * 1e9 * starts[i])
+                            + (e->cfg.channel_width * 1e9 * (n / 2.0));
+                vals[i] = osnr_observation(e, p, bw, fc, Pw, e->mod_thr[m]);
+                if (vals[i] > best) best = vals[i];
+                om += vals[i];
+                if (vals[i] >= 0) mask[((size_t)k * M + mi) * S + starts[i]] = 1;   /* :743-763 */
+            }
+            if (cnt > 0) {
+                om /= cnt;
+                for (int i = 0; i < cnt; i++) ov += (vals[i] - om) * (vals[i] - om);
+                ov /= cnt;
+            }
+            double tot = 0; for (int j = 0; j < S; j++) tot += avail[j];
+            /* block sizes :635-650 */
+            int nb = 0, cur_len = 0; double bsum = 0;
+            int32_t *blk = starts;   /* reuse */
+            for (int j = 0; j < S; j++) {
+                if (avail[j] == 1) cur_len++;
+                else { if (cur_len > 0) blk[nb++] = cur_len; cur_len = 0; }
+            }
+            if (cur_len > 0) blk[nb++] = cur_len;
+            double mb = 0.0, sb = 0.0;
+            if (nb > 0) {
+                for (int i = 0; i < nb; i++) bsum += blk[i];
+                double bm = bsum / nb, bv = 0;
+                for (int i = 0; i < nb; i++) bv += (blk[i] - bm) * (blk[i] - bm);
+                mb = ((bm - 4.0) / 4.0) / 100.0; sb = sqrt(bv / nb) / 100.0;
+            }
+            f[0] = (float)((double)cnt / S);
+            f[1] = (float)(mean_s / (S - 1)); f[2] = (float)(std_s / (S - 1));
+            double adj = (n - 5.5) / 3.5; f[3] = (float)(adj > 0.0 ? adj : 0.0);
+            f[4] = (float)(2.0 * (tot - 0.5 * S) / S);
+            f[5] = (float)mb; f[6] = (float)sb;
+            f[7] = (float)best; f[8] = (float)om; f[9] = (float)ov;
+            f[10] = (float)(2.0 * ((tot / S) - 0.5));
+            f[11] = (float)(max_s / (S - 1));
+        }
+    }
+    mask[(size_t)K * M * S] = 1;                                       /* :766 */
+    free(starts); free(vals);
+}
+
 /* ---- the JOCN loop (examples/JOCN_Benchmark_2024/graph_load.py:157-164) for one replica ------------------------ */
 /* nsteps iterations of {policy, step}; auto-reset after a terminal step.  out: [nsteps] or NULL. */
 int orc_run_first_fit(orc_env *e, int nsteps, ongym_step_rec *out) {

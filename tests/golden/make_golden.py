@@ -389,6 +389,51 @@ def export_kats():
     print("kats:", len(cand), "candidate cases,", len(gn), "GN cases")
 
 
+def run_observation(tag, topo_name, seed, load, S, steps, bit_rates=(10, 40, 100, 400), launch_power_dbm=0.0,
+                    margin=0.0, k=5):
+    """gen_observation=True: observation vector (qrmsa.pyx:583-781) and action mask at every step of a first-fit run."""
+    topo = load_topology(topo_name, k)
+    random.Random = seeded_random(seed)
+    try:
+        env = QRMSAEnvWrapper(
+            topology=topo, seed=10, allow_rejection=True, load=load, episode_length=steps + 50,
+            num_spectrum_resources=S, launch_power_dbm=launch_power_dbm, bandwidth=S * 12.5e9,
+            frequency_start=3e8 / 1565e-9, frequency_slot_bandwidth=12.5e9, bit_rate_selection="discrete",
+            bit_rates=bit_rates, margin=margin, file_name="", measure_disruptions=False, k_paths=k,
+            modulations_to_consider=6, defragmentation=False, n_defrag_services=0, gen_observation=True)
+    finally:
+        random.Random = _OrigRandom
+    reqs = [request_tuple(env)]
+    obs0, info0 = env.reset()
+    reqs.append(request_tuple(env))
+    obs_l, mask_l, act_l = [obs0], [np.packbits(info0["mask"], bitorder="little")], []
+    for i in range(steps):
+        action, _, _ = H.heuristic_shortest_available_path_first_fit_best_modulation(env)
+        obs, reward, done, _, info = env.step(int(action))
+        act_l.append(int(action))
+        obs_l.append(obs); mask_l.append(np.packbits(info["mask"], bitorder="little"))
+        reqs.append(request_tuple(env))
+        assert env.env.max_modulation_idx == 5
+    reqs_a = np.array(reqs, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, f"{tag}.npz"),
+                        req_at=reqs_a[:, 0].astype(np.float32), req_ht=reqs_a[:, 1].astype(np.float32),
+                        req_src=reqs_a[:, 2].astype(np.int32), req_dst=reqs_a[:, 3].astype(np.int32),
+                        req_br=reqs_a[:, 4].astype(np.float32), action=np.array(act_l, np.int32),
+                        obs=np.stack(obs_l).astype(np.float32), mask=np.stack(mask_l))
+    json.dump(dict(tag=tag, topology=topo_name, seed=seed, load=load, S=S, steps=steps, bit_rates=list(bit_rates),
+                   launch_power_dbm=launch_power_dbm, margin=margin, k_paths=k, episode_length=steps + 50,
+                   bit_rate_selection="discrete", frequency_start=3e8 / 1565e-9, slot_bw=12.5e9,
+                   mean_holding=10800.0, initial_resets=2, n_actions=int(env.env.action_space.n)),
+              open(os.path.join(HERE, f"{tag}.json"), "w"), indent=1)
+    print(f"{tag}: {steps} steps, obs dim {obs_l[0].shape[0]}, mask ones first/last {int(info0['mask'].sum())}/{int(info['mask'].sum())}")
+
+
+OBS = {
+    "obs_nsfnet320": dict(topo_name="nsfnet", seed=31, load=300, S=320, steps=120),
+    "obs_nsfnet320_dense": dict(topo_name="nsfnet", seed=32, load=2500, S=320, steps=160, margin=0.5,
+                                launch_power_dbm=-1.0),
+}
+
 TRAJ = {
     "traj_nsfnet320": dict(topo_name="nsfnet", seed=1234, load=300, S=320, episodes=3),
     "traj_nsfnet320_hi": dict(topo_name="nsfnet", seed=77, load=600, S=320, episodes=2,
@@ -415,6 +460,9 @@ def main():
     for tag, kw in TRAJ.items():
         if not want or tag in want:
             run_trajectory(tag, **kw)
+    for tag, kw in OBS.items():
+        if not want or tag in want:
+            run_observation(tag, **kw)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,67 @@
+"""Observation + action-mask kernel through the C ABI vs the reference's captured outputs and vs the
+oracle on random states. Tolerance: the observation is float32; features are held to 2e-6 relative / 2e-7 absolute,
+the mask bit-exact."""
+import numpy as np
+import pytest
+
+from common import golden_tables, holder_for, jocn_modulations, load_traj, traj_requests
+from optical_networking_gym import _native as nat
+from optical_networking_gym.envs.batched import BatchedQRMSAEnv
+from oracle_lib import OracleEnv
+from test_gpu_parity import make_env
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tag", ["obs_nsfnet320", "obs_nsfnet320_dense"])
+def test_observation_and_mask_vs_reference(tag):
+    meta, d = load_traj(tag)
+    env = make_env(meta, auto_reset=False)
+    env.set_requests(traj_requests(d))
+    for _ in range(meta["initial_resets"]):
+        env.reset()
+    for i in range(meta["steps"] + 1):
+        obs, mask = env.observe()
+        want_mask = np.unpackbits(d["mask"][i], bitorder="little")[:meta["n_actions"]]
+        np.testing.assert_array_equal(mask[0], want_mask, err_msg=f"mask step {i}")
+        np.testing.assert_allclose(obs[0], d["obs"][i], rtol=2e-6, atol=2e-7, err_msg=f"obs step {i}")
+        if i < meta["steps"]:
+            rec = env.step(np.array([d["action"][i]], np.int32))[0]
+            assert not rec["retry"] and not (rec["flags"] & nat.F_QOT_ERROR)
+
+
+@pytest.mark.parametrize("topo,S,load", [("nsfnet", 320, 500), ("nobel-eu", 320, 700), ("cost239", 192, 300)])
+def test_observation_vs_oracle_random_states(topo, S, load):
+    B = 12
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=S, batch=B, capacity=1024, load=load,
+              bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), auto_reset=True)
+    holder = nat.ConfigHolder(golden_tables(topo), **kw)
+    env = BatchedQRMSAEnv(tables=golden_tables(topo), modulations=jocn_modulations(), batch_size=B,
+                          num_spectrum_resources=S, capacity=1024, load=load, bit_rate_selection="discrete",
+                          bit_rates=(10, 40, 100, 400))
+    env.seed(77); env.reset()
+    env.step_policy(450, record=False)
+    obs, mask = env.observe()
+    pl = np.ctypeslib.as_array(holder.struct.path_len_norm, shape=(holder.struct.n_paths,))
+    for r in range(B):
+        o = OracleEnv(holder, replica=r)
+        o.seed(77); o.reset(); o.run_first_fit(450)
+        want_obs, want_mask = o.observe(pl, holder.struct.max_bit_rate)
+        np.testing.assert_array_equal(mask[r], want_mask, err_msg=f"mask replica {r}")
+        np.testing.assert_allclose(obs[r], want_obs, rtol=2e-6, atol=2e-7, err_msg=f"obs replica {r}")
+    assert mask[:, -1].all() and mask[:, :-1].any()
+
+
+def test_masked_actions_are_accepted_by_step():
+    """every action the mask allows is feasible: stepping it never raises the QoT error / retry."""
+    meta, d = load_traj("obs_nsfnet320_dense")
+    env = make_env(meta, batch=64, load=900, margin=0.0)   # the mask ignores the margin (qrmsa.pyx:757), step() does not
+    env.seed(5); env.reset()
+    env.step_policy(300, record=False)
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        _, mask = env.observe()
+        acts = np.array([rng.choice(np.flatnonzero(m)) for m in mask], np.int32)
+        rec = env.step(acts)
+        assert not rec["retry"].any() and not (rec["flags"] & nat.F_QOT_ERROR).any()
+        assert np.array_equal(rec["accepted"] == 0, acts == env.reject_action)

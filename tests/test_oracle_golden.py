@@ -138,3 +138,35 @@ def test_request_stream_is_deterministic_and_distributed():
     c = OracleEnv(h, replica=1)
     c.seed(42); c.reset()
     assert c.run_first_fit(400).tobytes() != ra.tobytes()
+
+
+# ---- observation() + action mask (gen_observation=True) ------------------------------------------------------------
+OBS_TAGS = ["obs_nsfnet320", "obs_nsfnet320_dense"]
+
+
+def obs_setup(tag):
+    meta, d = load_traj(tag)
+    h = holder_for(meta, capacity=1024)
+    reqs = traj_requests(d)
+    return meta, d, h, reqs
+
+
+@pytest.mark.parametrize("tag", OBS_TAGS)
+def test_observation_and_mask_vs_reference(tag):
+    """The reference's 368-float observation and 9601-entry action mask at every step of a first-fit run."""
+    meta, d, h, reqs = obs_setup(tag)
+    env = OracleEnv(h)
+    env.set_trace(reqs)
+    for _ in range(meta["initial_resets"]):
+        env.reset()
+    pl = np.ctypeslib.as_array(h.struct.path_len_norm, shape=(h.struct.n_paths,))
+    step = max(1, meta["steps"] // 25)
+    for i in range(meta["steps"] + 1):
+        if i % step == 0 or i == meta["steps"]:
+            obs, mask = env.observe(pl, h.struct.max_bit_rate)
+            want_mask = np.unpackbits(d["mask"][i], bitorder="little")[:meta["n_actions"]]
+            np.testing.assert_array_equal(mask, want_mask, err_msg=f"mask step {i}")
+            np.testing.assert_allclose(obs, d["obs"][i], rtol=2e-6, atol=2e-7, err_msg=f"obs step {i}")
+        if i < meta["steps"]:
+            rc, _ = env.step(int(d["action"][i]))
+            assert rc == 0
