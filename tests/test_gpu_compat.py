@@ -149,3 +149,24 @@ def test_unbuilt_features_fail_loudly():
     import networkx as nx
     with pytest.raises(KeyError, match="ksp"):
         QRMSAEnvWrapper(topology=nx.Graph(), gen_observation=False)
+
+
+def test_gen_observation_through_the_wrapper():
+    """gen_observation=True: reset()/step() return the reference's observation vector and info['mask']
+    (what MaskablePPO consumes through QRMSAEnvWrapper.action_masks(), wrappers/qrmsa_gym.py:74-75)."""
+    meta, d = load_traj("obs_nsfnet320")
+    topology = get_topology(bundled_topology_path("nsfnet_chen.txt"), None, jocn_modulations(), 80, 0.2, 4.5, 5)
+    env = QRMSAEnvWrapper(topology=topology, seed=10, allow_rejection=True, load=meta["load"],
+                          episode_length=meta["episode_length"], num_spectrum_resources=320, launch_power_dbm=0.0,
+                          bandwidth=4e12, frequency_start=3e8 / 1565e-9, frequency_slot_bandwidth=12.5e9,
+                          bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), margin=0, file_name="",
+                          k_paths=5, modulations_to_consider=6, gen_observation=True, requests=traj_requests(d))
+    obs, info = env.reset()
+    for i in range(25):
+        want_mask = np.unpackbits(d["mask"][i], bitorder="little")[:9601]
+        assert obs.shape == (368,) and obs.dtype == np.float32
+        np.testing.assert_allclose(obs, d["obs"][i], rtol=2e-6, atol=2e-7)
+        np.testing.assert_array_equal(info["mask"], want_mask)
+        np.testing.assert_array_equal(env.action_masks(), want_mask)
+        assert info["mask"][int(d["action"][i])] == 1          # the first-fit action is always inside the mask
+        obs, reward, done, truncated, info = env.step(int(d["action"][i]))
