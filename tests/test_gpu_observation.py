@@ -65,3 +65,28 @@ def test_masked_actions_are_accepted_by_step():
         rec = env.step(acts)
         assert not rec["retry"].any() and not (rec["flags"] & nat.F_QOT_ERROR).any()
         assert np.array_equal(rec["accepted"] == 0, acts == env.reject_action)
+
+
+def test_vec_env_masked_random_policy_rollout():
+    """VecEnv-shaped API: a masked random policy runs whole episodes; dones trigger the in-launch reset."""
+    from optical_networking_gym.envs.vec_env import QRMSAVecEnv
+    venv = QRMSAVecEnv(tables=golden_tables("nsfnet"), modulations=jocn_modulations(), num_envs=32, seed=3,
+                       num_spectrum_resources=320, capacity=512, load=400, episode_length=60,
+                       bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400))
+    obs = venv.reset()
+    assert obs.shape == (32, 368) and obs.dtype == np.float32
+    rng = np.random.default_rng(1)
+    finished = 0
+    for t in range(150):
+        masks = venv.action_masks()
+        assert masks.shape == (32, 9601) and masks[:, -1].all()
+        acts = [rng.choice(np.flatnonzero(m[:-1])) if m[:-1].any() and rng.random() < 0.95 else 9600 for m in masks]
+        obs, rew, dones, infos = venv.step(acts)
+        assert set(np.unique(rew)) <= {0.0, -6.0}
+        assert (rew == -6.0).sum() == sum(a == 9600 for a in acts)
+        for i in np.flatnonzero(dones):
+            assert 0.0 <= infos[i]["episode"]["episode_service_blocking_rate"] <= 1.0
+            finished += 1
+        assert dones.sum() == (32 if (t + 1) % 59 == 0 else 0)      # every replica terminates after 59 steps
+    assert finished == 64
+    venv.close()
