@@ -42,8 +42,12 @@ struct DevEnv {
     float cur_at, cur_ht, cur_br;            // current_service (C floats in the reference, envs/qrmsa.pyx:35-37)
     int32_t cur_src, cur_dst, cur_id;
     int32_t have_request;                    // _new_service (envs/qrmsa.pyx:1077-1078,1102)
-    float min_rel;                           // min release time over running services (+inf if none)
+    float min_rel;                           // unused (kept for layout)
     int32_t pad0;
+    // sum of Service.OSNR of the running episode = osnr_flushed - 10 log10(osnr_prod): the product takes one multiply per
+    // accepted service and one log10 per ~60 of them; both survive across launches so results do not depend on how
+    // the steps are partitioned into launches. st.episode_osnr_sum is refreshed from them at every store.
+    double osnr_flushed, osnr_prod;
 };
 
 struct Params {
@@ -143,6 +147,9 @@ struct Ctx {
     uint64_t pre_m0, pre_m1;
     int active;        // running services (wave-uniform, mirrored to e->st.active at store time)
     int lane_terms;    // per-lane interferer-link term counter (reduced once per launch)
+    // sum of Service.OSNR = -10 log10(acc) over accepted services, kept as -10 log10 of a running PRODUCT of the acc's
+    // (one multiply per step instead of one log10; folded into episode_osnr_sum by flush_osnr)
+    double osnr_prod;
     int gn_evals;      // wave-uniform
     int gn_skips;      // wave-uniform: evaluations decided by the ASE-only bound
     int paths_tried, path_hops;   // wave-uniform statistics
@@ -689,6 +696,11 @@ __device__ __forceinline__ void draw_next(Ctx &c) {
     __syncthreads();
 }
 
+// fold the running product into DevEnv.st.episode_osnr_sum (lane 0 only)
+__device__ __forceinline__ void flush_osnr(Ctx &c) {
+    if (c.osnr_prod != 1.0) { c.e->osnr_flushed += -10.0 * log10(c.osnr_prod); c.osnr_prod = 1.0; }
+}
+
 // ---- reset (envs/qrmsa.pyx:427-504) ----------------------------------------------------------------------------
 __device__ __forceinline__ void reset_env(Ctx &c) {
     const Params &P = c.P;
@@ -704,6 +716,7 @@ __device__ __forceinline__ void reset_env(Ctx &c) {
         for (int m = 0; m < 8; m++) s.episode_modulation_hist[m] = 0;
         s.bit_rate_requested = 0.0; s.bit_rate_provisioned = 0.0;   // :466-467
         s.episode_osnr_sum = 0.0;
+        e->osnr_flushed = 0.0; c.osnr_prod = 1.0;
         e->have_request = 0;
     }
     __syncthreads();
@@ -724,7 +737,7 @@ __device__ __forceinline__ void snapshot_terminal(DevEnv *e) {   // info of the 
         ? (s.episode_bit_rate_requested - s.episode_bit_rate_provisioned) / s.episode_bit_rate_requested : 0.0;
     for (int m = 0; m < 8; m++) s.last_modulation_hist[m] = s.episode_modulation_hist[m];
     // graph_load.py:181-185: mean of Service.OSNR over topology.graph["services"] (one entry per completed step)
-    s.last_mean_gsnr = s.episode_services_processed > 0 ? s.episode_osnr_sum / (double)s.episode_services_processed : 0.0;
+    s.last_mean_gsnr = s.episode_services_processed > 0 ? e->osnr_flushed / (double)s.episode_services_processed : 0.0;
 }
 
 // ---- one request: apply the choice (envs/qrmsa.pyx:838-1065) ----------------------------------------------------
@@ -770,8 +783,12 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
         r.osnr = 0.0; r.ase = 0.0; r.nli = 0.0; r.reward = 0.0; r.active = 0;
         double osnr = 0.0;
         if (outcome == 0) {
-            double g[3] = {-10.0 * log10(ch.g.ase + ch.g.nli), 0.0, 0.0};   // Service.OSNR = 10 log10(1/acc), once per step
-            if (rec) { g[1] = -10.0 * log10(ch.g.ase); g[2] = -10.0 * log10(ch.g.nli); }
+            // Service.OSNR = 10 log10(1/acc): per step only when a record is requested; the episode sum (mean_gsnr of
+            // graph_load.py:181-185) accumulates the product of the acc's and takes one log10 per ~60 services
+            double g[3] = {0.0, 0.0, 0.0};
+            if (rec) { g[0] = -10.0 * log10(ch.g.ase + ch.g.nli); g[1] = -10.0 * log10(ch.g.ase); g[2] = -10.0 * log10(ch.g.nli); }
+            c.osnr_prod *= (ch.g.ase + ch.g.nli);
+            if (c.osnr_prod < 1e-250) flush_osnr(c);
             rel = e->cur_at + e->cur_ht;   // float + float (:1329); compared as float32 (:1114-1115)
             uint32_t ra, rb;
             rec_pack<R32>(ch.path, ch.m0, ch.slot, ch.n, ch.mod, ra, rb);
@@ -792,12 +809,11 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
             r.reward = -6.0;                      // :992-995
             if (overflow) { r.flags |= ONGYM_F_OVERFLOW; s.flags |= ONGYM_F_OVERFLOW; }
         }
-        s.episode_osnr_sum += osnr;
         s.total_steps += 1;
         e->have_request = 0;
         // the info dict is computed before the next request is drawn (:996-1050); the step terminates the episode
         // iff that draw makes episode_services_processed reach episode_length (:1056)
-        if (s.episode_services_processed + 1 == P.episode_length) snapshot_terminal(e);
+        if (s.episode_services_processed + 1 == P.episode_length) { flush_osnr(c); snapshot_terminal(e); }
         if (rec) *rec = r;
     }
     if (outcome == 0) {
@@ -1031,6 +1047,7 @@ __device__ __forceinline__ void load_state(Ctx &c) {
     c.br_reg = (c.lane < P.n_bit_rates && P.n_bit_rates <= kWave) ? (float)P.bit_rates[c.lane] : 0.f;
     __syncthreads();
     c.active = c.e->st.active;
+    c.osnr_prod = c.e->osnr_prod > 0.0 ? c.e->osnr_prod : 1.0;
     c.pre_id = -1;
     if (c.e->have_request) prefetch_first_path(c, c.e->cur_src, c.e->cur_dst);
     // per-replica acceptance limits in the linear domain (see qot_ok)
@@ -1051,6 +1068,8 @@ __device__ __forceinline__ void store_state(Ctx &c) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) terms += __shfl_xor(terms, m);
     if (c.lane == 0) {
+        c.e->osnr_prod = c.osnr_prod;
+        c.e->st.episode_osnr_sum = c.e->osnr_flushed + (c.osnr_prod != 1.0 ? -10.0 * log10(c.osnr_prod) : 0.0);
         c.e->st.active = c.active;
         c.e->st.total_gn_evals += c.gn_evals;
         c.e->st.total_gn_shortcuts += c.gn_skips;
