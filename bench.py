@@ -113,7 +113,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
     from optical_networking_gym._dist import init_process_group, rank_seed, reduce_run_statistics
-    dist = init_process_group("nccl", local_rank) if world > 1 else None   # "nccl" is RCCL on ROCm
+    # under torch.distributed.run (RANK set) the process group is always created, also for one rank
+    dist = init_process_group("nccl", local_rank) if (world > 1 or "RANK" in os.environ) else None   # "nccl" = RCCL
 
     import __graft_entry__ as entry
     if rank == 0:

@@ -47,7 +47,8 @@ def csv_row(ep, st, n_mods, ep_time):
     return row + f",0,{ep_time:.2f},{st['last_mean_gsnr']}\n"
 
 
-def run_sweep(topology, *, n_episodes, episode_length, replicas_per_point, points, seed, common, monitor_names):
+def run_sweep(topology, *, n_episodes, episode_length, replicas_per_point, points, seed, common, monitor_names,
+              policy=0):
     """points: list of dicts with per-point overrides among launch_power_dbm / load / margin.
     Every point gets `replicas_per_point` replicas; each replica runs ceil(n_episodes / replicas_per_point) episodes.
     Writes one CSV per point (monitor_names[i]) with the reference's columns; returns per-point arrays of
@@ -74,7 +75,7 @@ def run_sweep(topology, *, n_episodes, episode_length, replicas_per_point, point
     ep_counter = [0] * P
     for _ in range(rounds):
         t0 = time.time()
-        env.step_policy(episode_length - 1, record=False)     # one episode of every replica (auto-reset at the end)
+        env.step_policy(episode_length - 1, record=False, policy=policy)   # one episode of every replica (auto-reset at the end)
         st = env.stats()
         dt = time.time() - t0
         for p in range(P):

@@ -36,7 +36,10 @@ enum {
 };
 
 /* policies fused on device; replaces optical_networking_gym/heuristics/heuristics.py:923-966 */
-enum { ONGYM_POLICY_FIRST_FIT = 0 };
+enum {
+    ONGYM_POLICY_FIRST_FIT = 0,      /* heuristic_shortest_available_path_first_fit_best_modulation, heuristics.py:923-966 */
+    ONGYM_POLICY_LOAD_BALANCING = 1  /* load_balancing_best_modulation, heuristics.py:547-627 (graph_load.py heuristic 4) */
+};
 
 /* ongym_step_rec.flags */
 enum {

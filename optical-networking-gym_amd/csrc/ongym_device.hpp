@@ -552,6 +552,69 @@ __device__ __forceinline__ void policy_first_fit(Ctx &c, int src, int dst, doubl
     ch.flags = (bres ? ONGYM_F_BLOCKED_RESOURCES : 0) | (bosnr ? ONGYM_F_BLOCKED_OSNR : 0);
 }
 
+
+// ---- load_balancing_best_modulation (heuristics/heuristics.py:547-627) ------------------------------------------
+// Same per-path search as first fit (best modulation, lowest feasible slot, GN check), but every path is examined and the
+// one with the fewest busy slots per hop wins; a path is skipped as soon as its load is not below the best so far.
+template <bool UNIFORM_ALPHA, bool R32>
+__device__ __forceinline__ void policy_load_balancing(Ctx &c, int src, int dst, double launch_power, double margin,
+                                                      Choice &ch) {
+    const Params &P = c.P;
+    const int M = P.n_mods, S = P.n_slots, max_mod = M - 1;
+    ch.action = P.k_paths * M * S; ch.route = -1; ch.mod = -1; ch.slot = -1; ch.n = 0; ch.hops = 0; ch.mylink = 0;
+    ch.path = -1; ch.m0 = 0; ch.g.ase = ch.g.nli = 0.0; ch.flags = 0;
+    int any_res = 0, any_osnr = 0;
+    double lowest_load = INFINITY;
+    for (int k = 0; k < P.k_paths; k++) {
+        int path = k == 0 ? c.pre_id : G(P.pair_paths)[(src * P.n_nodes + dst) * P.k_paths + k];
+        if (path < 0) break;
+        PathRef p;
+        if (k == 0) { p.id = path; p.hops = c.pre_hops; p.mylink = c.pre_mylink; p.m0 = c.pre_m0; p.m1 = c.pre_m1; }
+        else p = load_path(c, path);
+        c.paths_tried++; c.path_hops += p.hops;
+        const uint64_t free_ext = path_free_ext(c, p);
+        // np.sum(available_slots == 0) / len(path.links): busy slots of the path row (virtual guard bit excluded)
+        const uint64_t aw = (c.lane == (S >> 6)) ? (free_ext & ~(1ull << (S & 63))) : free_ext;
+        int freecnt = c.lane < P.row_words ? __popcll((unsigned long long)aw) : 0;
+#pragma unroll
+        for (int mm = 8; mm >= 1; mm >>= 1) freecnt += __shfl_xor(freecnt, mm);     // words live in lanes 0..15
+        freecnt = uniform_i32(freecnt);
+        const double current_load = (double)(S - freecnt) / (double)p.hops;
+        if (current_load >= lowest_load) continue;
+        uint64_t runs = free_ext;
+        int r = 1, L = -1;
+        for (int m = max_mod; m >= 0; m--) {
+            int n = uniform_i32(c.nreq[m]);
+            if (n <= 0) continue;
+            if (n + 1 < r) { runs = free_ext; r = 1; }
+            runs = run_and(runs, r, n + 1);
+            int first = first_set(runs);
+            if (first < 0) { any_res = 1; continue; }
+            if (P.ase_shortcut) {   // exact lower bound, see policy_first_fit
+                double bw = P.slot_bw * n;
+                double fc = P.f0 + (P.slot_bw * first) + (P.slot_bw * (n / 2.0));
+                double lb = (bw * fc * G(P.path_ase)[path]) * c.rp[0];
+                if (UNIFORM_ALPHA) lb += (G(P.nli_coef)[n] * c.rp[1]) * (G(P.path_w1)[path] * G(P.self_asinh)[n]);
+                if (uniform_i32(lb >= c.lim[m] * (1.0 + 1e-9))) { any_osnr = 1; c.gn_skips++; continue; }
+            }
+            if (L < 0) L = gn_build_list<R32>(c, p.m0, p.m1);
+            GnLin g = gn_eval<UNIFORM_ALPHA, R32>(c, p, L, first, n);
+            if (qot_ok(c, g, m, margin)) {
+                lowest_load = current_load;
+                ch.action = k * M * S + (max_mod - m) * S + first;
+                ch.route = k; ch.mod = m; ch.slot = first; ch.n = n; ch.hops = p.hops; ch.mylink = p.mylink;
+                ch.path = path; ch.m0 = p.m0;
+                ch.g.ase = uniform_f64(g.ase); ch.g.nli = uniform_f64(g.nli);
+                break;
+            }
+            any_osnr = 1;
+        }
+    }
+    if (ch.route >= 0) { ch.flags = 0; return; }
+    if (any_osnr) any_res = 0;
+    ch.flags = (any_res ? ONGYM_F_BLOCKED_RESOURCES : 0) | (any_osnr ? ONGYM_F_BLOCKED_OSNR : 0);
+}
+
 // ---- decode + validate an external action (envs/qrmsa.pyx:801-834, 867-909) ------------------------------------
 // returns 0 accept (GN evaluated, passes), 1 reject action, 2 slots not free (retry), 3 QoT infeasible
 template <bool UNIFORM_ALPHA, bool R32>

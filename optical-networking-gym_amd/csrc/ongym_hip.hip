@@ -18,7 +18,7 @@ using namespace ongym;
 // ---------------------------------------------------------------------------------------------------------------
 // WAVES = waves per SIMD the register allocation is bounded for: 5 when the replica's LDS block is <= 8 KiB (20 replicas
 // per CU), else 4
-template <bool UA, bool R32, int WAVES>
+template <bool UA, bool R32, int WAVES, int POLICY>
 __global__ __launch_bounds__(64, WAVES) void k_run(const Params *__restrict__ Pp, int mode, int nsteps, const int32_t *actions, int32_t *act_out,
                                             uint8_t *flag_out, ongym_step_rec *out) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -60,7 +60,8 @@ __global__ __launch_bounds__(64, WAVES) void k_run(const Params *__restrict__ Pp
         if (mode == kModeActionStep) {
             outcome = evaluate_action<UA, R32>(c, src, dst, lp, mg, actions[c.replica], ch);
         } else {
-            policy_first_fit<UA, R32>(c, src, dst, lp, mg, ch);
+            if (POLICY == ONGYM_POLICY_LOAD_BALANCING) policy_load_balancing<UA, R32>(c, src, dst, lp, mg, ch);
+            else policy_first_fit<UA, R32>(c, src, dst, lp, mg, ch);
             outcome = ch.route >= 0 ? 0 : 1;
         }
         if (mode == kModePolicyOnly) {
@@ -475,8 +476,10 @@ static int build(ongym_env *env, const ongym_config *c) {
     if (env->lds > 64 * 1024) {
         if (env->lds > 160 * 1024) return fail_arg(env, "state does not fit the 160 KiB LDS: lower capacity", ONGYM_E_LIMIT);
 #define ONGYM_SET_LDS(K) HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->lds))
-        ONGYM_SET_LDS((k_run<true, true, 4>)); ONGYM_SET_LDS((k_run<true, false, 4>));
-        ONGYM_SET_LDS((k_run<false, true, 4>)); ONGYM_SET_LDS((k_run<false, false, 4>));
+        ONGYM_SET_LDS((k_run<true, true, 4, 0>)); ONGYM_SET_LDS((k_run<true, false, 4, 0>));
+        ONGYM_SET_LDS((k_run<false, true, 4, 0>)); ONGYM_SET_LDS((k_run<false, false, 4, 0>));
+        ONGYM_SET_LDS((k_run<true, true, 4, 1>)); ONGYM_SET_LDS((k_run<true, false, 4, 1>));
+        ONGYM_SET_LDS((k_run<false, true, 4, 1>)); ONGYM_SET_LDS((k_run<false, false, 4, 1>));
         ONGYM_SET_LDS((k_query<true, true>)); ONGYM_SET_LDS((k_query<true, false>));
         ONGYM_SET_LDS((k_query<false, true>)); ONGYM_SET_LDS((k_query<false, false>));
         ONGYM_SET_LDS(k_reset);
@@ -634,18 +637,21 @@ int ongym_reset(ongym_env *env, const uint8_t *mask) {
     return ONGYM_OK;
 }
 
-static int launch_run(ongym_env *env, int mode, int nsteps, const int32_t *d_actions, int32_t *d_act_out,
+static int launch_run(ongym_env *env, int mode, int policy, int nsteps, const int32_t *d_actions, int32_t *d_act_out,
                       uint8_t *d_flag_out, ongym_step_rec *d_out) {
     HIP_TRY(env, hipEventRecord(env->ev0, env->stream));
     const dim3 grid(env->P.batch), block(64);
 #define ONGYM_LAUNCH_RUN(UA, R)                                                                                    \
     do {                                                                                                           \
-        if (env->lds <= 8192)                                                                                      \
-            hipLaunchKernelGGL((k_run<UA, R, 5>), grid, block, env->lds, env->stream, env->d_P, mode, nsteps,       \
-                               d_actions, d_act_out, d_flag_out, d_out);                                           \
+        if (policy == ONGYM_POLICY_LOAD_BALANCING)                                                                 \
+            hipLaunchKernelGGL((k_run<UA, R, 4, ONGYM_POLICY_LOAD_BALANCING>), grid, block, env->lds, env->stream,  \
+                               env->d_P, mode, nsteps, d_actions, d_act_out, d_flag_out, d_out);                   \
+        else if (env->lds <= 8192)                                                                                 \
+            hipLaunchKernelGGL((k_run<UA, R, 5, ONGYM_POLICY_FIRST_FIT>), grid, block, env->lds, env->stream,       \
+                               env->d_P, mode, nsteps, d_actions, d_act_out, d_flag_out, d_out);                   \
         else                                                                                                       \
-            hipLaunchKernelGGL((k_run<UA, R, 4>), grid, block, env->lds, env->stream, env->d_P, mode, nsteps,       \
-                               d_actions, d_act_out, d_flag_out, d_out);                                           \
+            hipLaunchKernelGGL((k_run<UA, R, 4, ONGYM_POLICY_FIRST_FIT>), grid, block, env->lds, env->stream,       \
+                               env->d_P, mode, nsteps, d_actions, d_act_out, d_flag_out, d_out);                   \
     } while (0)
     if (env->P.uniform_alpha) { if (env->P.rec32) ONGYM_LAUNCH_RUN(true, true); else ONGYM_LAUNCH_RUN(true, false); }
     else { if (env->P.rec32) ONGYM_LAUNCH_RUN(false, true); else ONGYM_LAUNCH_RUN(false, false); }
@@ -666,7 +672,7 @@ static int ensure_out(ongym_env *env, size_t n) {
 
 int ongym_step_policy(ongym_env *env, int32_t policy, int32_t nsteps, ongym_step_rec *out) {
     if (!env) return ONGYM_E_ARG;
-    if (policy != ONGYM_POLICY_FIRST_FIT) return fail_arg(env, "unknown policy id");
+    if (policy != ONGYM_POLICY_FIRST_FIT && policy != ONGYM_POLICY_LOAD_BALANCING) return fail_arg(env, "unknown policy id");
     if (nsteps <= 0) return fail_arg(env, "nsteps must be positive");
     if (!env->has_source) { env->err = "no request source: call ongym_seed or ongym_set_requests first"; return ONGYM_E_STATE; }
     HIP_TRY(env, hipSetDevice(env->cfg.device));
@@ -674,12 +680,12 @@ int ongym_step_policy(ongym_env *env, int32_t policy, int32_t nsteps, ongym_step
     if (out && !env->cfg.io_device) {
         size_t n = (size_t)nsteps * env->P.batch;
         if ((rc = ensure_out(env, n))) return rc;
-        if ((rc = launch_run(env, kModePolicyStep, nsteps, nullptr, nullptr, nullptr, env->d_out))) return rc;
+        if ((rc = launch_run(env, kModePolicyStep, policy, nsteps, nullptr, nullptr, nullptr, env->d_out))) return rc;
         HIP_TRY(env, hipMemcpyAsync(out, env->d_out, n * sizeof(ongym_step_rec), hipMemcpyDeviceToHost, env->stream));
         HIP_TRY(env, hipStreamSynchronize(env->stream));
         return ONGYM_OK;
     }
-    return launch_run(env, kModePolicyStep, nsteps, nullptr, nullptr, nullptr, out);
+    return launch_run(env, kModePolicyStep, policy, nsteps, nullptr, nullptr, nullptr, out);
 }
 
 int ongym_step_actions(ongym_env *env, const int32_t *actions, ongym_step_rec *out) {
@@ -687,13 +693,13 @@ int ongym_step_actions(ongym_env *env, const int32_t *actions, ongym_step_rec *o
     if (!env->has_source) { env->err = "no request source: call ongym_seed or ongym_set_requests first"; return ONGYM_E_STATE; }
     HIP_TRY(env, hipSetDevice(env->cfg.device));
     int rc;
-    if (env->cfg.io_device) return launch_run(env, kModeActionStep, 1, actions, nullptr, nullptr, out);
+    if (env->cfg.io_device) return launch_run(env, kModeActionStep, ONGYM_POLICY_FIRST_FIT, 1, actions, nullptr, nullptr, out);
     HIP_TRY(env, hipMemcpyAsync(env->d_actions, actions, (size_t)env->P.batch * 4, hipMemcpyHostToDevice, env->stream));
     if (out) {
         if ((rc = ensure_out(env, (size_t)env->P.batch))) return rc;
-        if ((rc = launch_run(env, kModeActionStep, 1, env->d_actions, nullptr, nullptr, env->d_out))) return rc;
+        if ((rc = launch_run(env, kModeActionStep, ONGYM_POLICY_FIRST_FIT, 1, env->d_actions, nullptr, nullptr, env->d_out))) return rc;
         HIP_TRY(env, hipMemcpyAsync(out, env->d_out, (size_t)env->P.batch * sizeof(ongym_step_rec), hipMemcpyDeviceToHost, env->stream));
-    } else if ((rc = launch_run(env, kModeActionStep, 1, env->d_actions, nullptr, nullptr, nullptr))) return rc;
+    } else if ((rc = launch_run(env, kModeActionStep, ONGYM_POLICY_FIRST_FIT, 1, env->d_actions, nullptr, nullptr, nullptr))) return rc;
     HIP_TRY(env, hipStreamSynchronize(env->stream));
     return ONGYM_OK;
 }
@@ -739,11 +745,11 @@ int ongym_observe(ongym_env *env, float *obs, uint8_t *mask) {
 
 int ongym_policy_actions(ongym_env *env, int32_t policy, int32_t *actions, uint8_t *flags) {
     if (!env || !actions) return env ? fail_arg(env, "null actions") : ONGYM_E_ARG;
-    if (policy != ONGYM_POLICY_FIRST_FIT) return fail_arg(env, "unknown policy id");
+    if (policy != ONGYM_POLICY_FIRST_FIT && policy != ONGYM_POLICY_LOAD_BALANCING) return fail_arg(env, "unknown policy id");
     HIP_TRY(env, hipSetDevice(env->cfg.device));
     int rc;
-    if (env->cfg.io_device) return launch_run(env, kModePolicyOnly, 1, nullptr, actions, flags, nullptr);
-    if ((rc = launch_run(env, kModePolicyOnly, 1, nullptr, env->d_act_out, env->d_flag_out, nullptr))) return rc;
+    if (env->cfg.io_device) return launch_run(env, kModePolicyOnly, policy, 1, nullptr, actions, flags, nullptr);
+    if ((rc = launch_run(env, kModePolicyOnly, policy, 1, nullptr, env->d_act_out, env->d_flag_out, nullptr))) return rc;
     HIP_TRY(env, hipMemcpyAsync(actions, env->d_act_out, (size_t)env->P.batch * 4, hipMemcpyDeviceToHost, env->stream));
     if (flags) HIP_TRY(env, hipMemcpyAsync(flags, env->d_flag_out, (size_t)env->P.batch, hipMemcpyDeviceToHost, env->stream));
     HIP_TRY(env, hipStreamSynchronize(env->stream));

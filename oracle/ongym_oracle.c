@@ -413,6 +413,50 @@ int orc_policy_first_fit(orc_env *e, int *blocked_resources, int *blocked_osnr) 
     return action;
 }
 
+/* ---- load_balancing_best_modulation (heuristics/heuristics.py:547-627) ------------------------------------------ */
+int orc_policy_load_balancing(orc_env *e, int *blocked_resources, int *blocked_osnr) {
+    int any_res = 0, any_osnr = 0, have = 0;
+    int S = e->cfg.n_slots, K = e->cfg.k_paths, N = e->cfg.n_nodes;
+    int32_t *avail = e->scratch_avail;
+    int solution = orc_reject_action(e);
+    double lowest_load = INFINITY;
+    for (int k = 0; k < K; k++) {
+        int p = e->pair_paths[(e->cur.src * N + e->cur.dst) * K + k];
+        if (p < 0) break;
+        e->total_paths++; e->total_hops += e->path_hops[p];
+        orc_available(e, p, avail);
+        int busy = 0;
+        for (int j = 0; j < S; j++) busy += (avail[j] == 0);
+        double current_load = (double)busy / (double)e->path_hops[p];   /* np.sum(avail == 0) / len(path.links) */
+        if (current_load >= lowest_load) continue;
+        for (int m = e->max_mod_idx; m >= 0; m--) {
+            int req = orc_number_slots(e, e->cur.bit_rate, m);
+            if (req <= 0) continue;
+            int32_t first;
+            int cnt = orc_candidates(avail, S, req, &first, 1);
+            if (cnt == 0) { any_res = 1; continue; }
+            double o[3];
+            gn_state(e, p, first, req, o, 1);
+            if (o[0] >= e->mod_thr[m] + e->margin) {
+                lowest_load = current_load;
+                solution = orc_encode_action(e, k, m, first);
+                have = 1;
+                break;
+            }
+            any_osnr = 1;
+        }
+    }
+    if (have) { *blocked_resources = 0; *blocked_osnr = 0; return solution; }
+    if (any_osnr) any_res = 0;
+    *blocked_resources = any_res; *blocked_osnr = any_osnr;
+    return solution;
+}
+
+int orc_policy(orc_env *e, int policy, int *bres, int *bosnr) {
+    return policy == ONGYM_POLICY_LOAD_BALANCING ? orc_policy_load_balancing(e, bres, bosnr)
+                                                 : orc_policy_first_fit(e, bres, bosnr);
+}
+
 /* ---- reward (envs/qrmsa.pyx:1266-1285): only the not-accepted branch returns a value (quirk Q1) --------------- */
 static double reward(const orc_env *e) {
     double failed_ratio = (double)(e->ep_processed - e->ep_accepted) / (double)e->ep_processed;
@@ -668,10 +712,10 @@ void orc_observe(orc_env *e, const double *path_len_norm, double max_bit_rate, f
 
 /* ---- the JOCN loop (examples/JOCN_Benchmark_2024/graph_load.py:157-164) for one replica ------------------------ */
 /* nsteps iterations of {policy, step}; auto-reset after a terminal step.  out: [nsteps] or NULL. */
-int orc_run_first_fit(orc_env *e, int nsteps, ongym_step_rec *out) {
+int orc_run_policy(orc_env *e, int policy, int nsteps, ongym_step_rec *out) {
     for (int i = 0; i < nsteps; i++) {
         int bres, bosnr;
-        int a = orc_policy_first_fit(e, &bres, &bosnr);
+        int a = orc_policy(e, policy, &bres, &bosnr);
         ongym_step_rec r;
         int rc = orc_step(e, a, &r);
         if (rc) return rc;
@@ -681,6 +725,10 @@ int orc_run_first_fit(orc_env *e, int nsteps, ongym_step_rec *out) {
         if (r.terminated && e->cfg.auto_reset) orc_reset(e);
     }
     return 0;
+}
+
+int orc_run_first_fit(orc_env *e, int nsteps, ongym_step_rec *out) {
+    return orc_run_policy(e, ONGYM_POLICY_FIRST_FIT, nsteps, out);
 }
 
 /* B independent replicas, OpenMP over replicas (the reference's own fan-out is one process per simulation,

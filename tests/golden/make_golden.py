@@ -170,7 +170,7 @@ def link_state(env, link):
 
 def run_trajectory(tag, topo_name, seed, load, S, episodes, episode_length=1000, bit_rates=(10, 40, 100, 400),
                    launch_power_dbm=0.0, margin=0.0, bit_rate_selection="discrete", scripted=False,
-                   gn_every=41, snap_steps=(100, 400, 700, 998), k=5):
+                   gn_every=41, snap_steps=(100, 400, 700, 998), k=5, policy="first_fit"):
     topo = load_topology(topo_name, k)
     nodes = list(topo.nodes())
     gn_samples = []
@@ -198,6 +198,8 @@ def run_trajectory(tag, topo_name, seed, load, S, episodes, episode_length=1000,
             n_defrag_services=0, gen_observation=False)
     finally:
         random.Random = _OrigRandom
+    policy_fn = {"first_fit": H.heuristic_shortest_available_path_first_fit_best_modulation,
+                 "load_balancing": H.load_balancing_best_modulation}[policy]
     env = wrapper
     reqs, kinds = [], []
     reqs.append(request_tuple(env)); kinds.append(0)   # drawn by the constructor's own reset() (qrmsa.pyx:414-415)
@@ -216,7 +218,7 @@ def run_trajectory(tag, topo_name, seed, load, S, episodes, episode_length=1000,
         estep = 0
         while not done:
             cur = env.env.current_service
-            action, bres, bosnr = H.heuristic_shortest_available_path_first_fit_best_modulation(env)
+            action, bres, bosnr = policy_fn(env)
             retry = 0
             if scripted:
                 if gstep % 7 == 3:
@@ -299,7 +301,8 @@ def run_trajectory(tag, topo_name, seed, load, S, episodes, episode_length=1000,
                 margin=margin, bit_rate_selection=bit_rate_selection, scripted=scripted, k_paths=k,
                 frequency_start=3e8 / 1565e-9, slot_bw=12.5e9, mean_holding=10800.0,
                 terminal_infos=terminal_infos, n_steps=len(steps), n_requests=len(reqs),
-                launch_power_w=float(env.env.launch_power), reject_action=int(reject), initial_resets=3)
+                launch_power_w=float(env.env.launch_power), reject_action=int(reject), initial_resets=3,
+                policy=policy)
     np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **out)
     json.dump(meta, open(os.path.join(HERE, f"{tag}.json"), "w"), indent=1)
     acc = out["st_accepted"].mean()
@@ -447,6 +450,10 @@ TRAJ = {
     "traj_ring4": dict(topo_name="ring4", seed=11, load=30, S=64, episodes=2, episode_length=300,
                        snap_steps=(50, 200)),
     "traj_nsfnet320_scripted": dict(topo_name="nsfnet", seed=4321, load=300, S=320, episodes=1, scripted=True),
+    # load_balancing_best_modulation (heuristics.py:547-627), heuristic 4 of graph_load.py:116-125
+    "traj_nsfnet320_lb": dict(topo_name="nsfnet", seed=8, load=500, S=320, episodes=2, policy="load_balancing"),
+    "traj_nobeleu320_lb": dict(topo_name="nobel-eu", seed=18, load=700, S=320, episodes=1, policy="load_balancing",
+                               launch_power_dbm=1.0),
 }
 
 

@@ -49,6 +49,8 @@ def lib():
         L.orc_decode_action.argtypes = [vp, C.c_int, vp]
         L.orc_reject_action.argtypes = [vp]
         L.orc_policy_first_fit.argtypes = [vp, vp, vp]
+        L.orc_policy.argtypes = [vp, C.c_int, vp, vp]
+        L.orc_run_policy.argtypes = [vp, C.c_int, C.c_int, vp]
         L.orc_step.argtypes = [vp, C.c_int, vp]
         L.orc_stats.argtypes = [vp, vp]
         L.orc_grid.argtypes = [vp, vp]
@@ -133,6 +135,18 @@ class OracleEnv:
         a, b = C.c_int(0), C.c_int(0)
         act = self.L.orc_policy_first_fit(self.h, C.byref(a), C.byref(b))
         return act, bool(a.value), bool(b.value)
+
+    def policy(self, policy_id: int):
+        a, b = C.c_int(0), C.c_int(0)
+        act = self.L.orc_policy(self.h, policy_id, C.byref(a), C.byref(b))
+        return act, bool(a.value), bool(b.value)
+
+    def run_policy(self, policy_id: int, nsteps: int) -> np.ndarray:
+        rec = np.zeros(nsteps, STEP_DTYPE)
+        rc = self.L.orc_run_policy(self.h, policy_id, nsteps, rec.ctypes.data)
+        if rc:
+            raise RuntimeError(f"oracle run failed rc={rc}")
+        return rec
 
     def step(self, action: int):
         rec = np.zeros(1, STEP_DTYPE)

@@ -170,3 +170,24 @@ def test_observation_and_mask_vs_reference(tag):
         if i < meta["steps"]:
             rc, _ = env.step(int(d["action"][i]))
             assert rc == 0
+
+
+# ---- load_balancing_best_modulation (heuristics.py:547-627) -----------------------------------------------------------
+@pytest.mark.parametrize("tag", ["traj_nsfnet320_lb", "traj_nobeleu320_lb"])
+def test_load_balancing_trajectory(tag):
+    meta, d = load_traj(tag)
+    assert meta["policy"] == "load_balancing"
+    env = OracleEnv(holder_for(meta))
+    env.set_trace(traj_requests(d))
+    for _ in range(meta["initial_resets"]):
+        env.reset()
+    for i in range(meta["n_steps"]):
+        act, bres, bosnr = env.policy(1)
+        assert act == d["st_action"][i], f"step {i}: action {act} != {d['st_action'][i]}"
+        assert bres == bool(d["st_bres"][i]) and bosnr == bool(d["st_bosnr"][i]), f"step {i} flags"
+        rc, r = env.step(act)
+        assert rc == 0 and r["accepted"] == d["st_accepted"][i] and r["active"] == d["st_active"][i]
+        if r["accepted"]:
+            np.testing.assert_allclose(r["osnr"], d["st_osnr"][i], rtol=GSNR_RTOL)
+        if r["terminated"]:
+            env.reset()
