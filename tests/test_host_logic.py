@@ -197,3 +197,24 @@ def test_two_rank_statistics_reduction_gloo(tmp_path):
             rec = o.run_first_fit(150); steps += len(rec); acc += int(rec["accepted"].sum())
     assert got["delta"] == [float(steps), float(acc)]
     assert got["dt_max"] == 2.0 and got["k_ms"] == 20.0
+
+
+# ---- the reference's own unit tests, restated (tests/test_utils.py, tests/test_rmsa.py of the reference) -----------------
+def test_span_link_and_rmsa_plumbing():
+    from optical_networking_gym.envs.rmsa import RMSAEnv
+    from optical_networking_gym.topology import Link, Span
+    s = Span(length=80, attenuation=0.2, noise_figure=4.5)
+    assert s.attenuation_normalized != 0 and s.noise_figure_normalized != 0
+    before = s.attenuation_normalized
+    s.set_attenuation(0.3)
+    assert s.attenuation_normalized != before
+    before = s.noise_figure_normalized
+    s.set_noise_figure(6)
+    assert s.noise_figure_normalized != before and str(s) != ""
+    spans = tuple(Span(length=10.0 * (i + 1), attenuation=0.2, noise_figure=4.5) for i in range(5))
+    assert len(Link(id=0, node1="t", node2="d", length=150.0, spans=spans).spans) == 5
+    # BASELINE config 1: get_topology(nsfnet_chen.txt, "NSFNET", mods, 80, 0.2, 4.5, 5) + RMSAEnv(topology, 360)
+    topology = get_topology(bundled_topology_path("nsfnet_chen.txt"), "NSFNET", jocn_modulations(), 80, 0.2, 4.5, 5)
+    env = RMSAEnv(topology=topology, num_spectrum_resources=360)
+    assert env.spectrum_use.shape == (22, 360) and topology.name == "NSFNET"
+    assert len(topology.graph["ksp"]["1", "13"]) == 5 and topology.graph["ksp"]["1", "13"][0].hops == 3
