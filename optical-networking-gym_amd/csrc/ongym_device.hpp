@@ -920,7 +920,8 @@ __device__ __forceinline__ double wave_max_f64(double v) {
 }
 
 template <bool R32>
-__device__ __forceinline__ void observe_env(Ctx &c, double *Fx, float *obs, uint8_t *mask) {
+__device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, uint16_t *xlist, uint8_t *needx,
+                                            float *obs, uint8_t *mask) {
     const Params &P = c.P;
     const int K = P.k_paths, M = P.n_mods, S = P.n_slots, N = P.n_nodes;
     const int nx = 2 * S + 1, W = P.row_words;
@@ -972,7 +973,41 @@ __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, float *obs, uint
         const double len2 = (double)wave_sum_i32(len2_l);
         // ---- interferer field F(x)
         const int L = gn_build_list<R32>(c, p.m0, p.m1);
-        for (int x = c.lane; x < nx + 1; x += kWave) Fx[x] = 0.0;
+        // valid starts of every modulation (run-AND words, lane w = word w) and the candidate centres x = 2s + n they
+        // produce: the field is only needed there (a loaded network has few valid starts)
+        for (int x = c.lane; x < nx + 1; x += kWave) { Fx[x] = 0.0; needx[x] = 0; }
+        {
+            uint64_t runs0 = free_ext;
+            int r0 = 1;
+            for (int mi = 0; mi < M; mi++) {
+                const int n = uniform_i32(c.nreq[M - 1 - mi]);
+                uint64_t v = 0;
+                if (n > 0 && n <= S) {
+                    if (n + 1 < r0) { runs0 = free_ext; r0 = 1; }
+                    runs0 = run_and(runs0, r0, n + 1);
+                    v = runs0;
+                }
+                if (c.lane < kMaxRowWords) Vw[mi * kMaxRowWords + c.lane] = v;
+            }
+        }
+        __syncthreads();
+        for (int mi = 0; mi < M; mi++) {
+            const int n = uniform_i32(c.nreq[M - 1 - mi]);
+            for (int i = 0; i < W; i++) {
+                const uint64_t w = Vw[mi * kMaxRowWords + i];
+                const int sl = i * 64 + c.lane;
+                if (((w >> c.lane) & 1ull) && sl < S) needx[2 * sl + n] = 1;
+            }
+        }
+        __syncthreads();
+        int nxl = 0;
+        for (int x0 = 0; x0 < nx; x0 += kWave) {
+            const int x = x0 + c.lane;
+            const bool need = x < nx && needx[x];
+            const uint64_t bal = __ballot(need);
+            if (need) xlist[nxl + __popcll((unsigned long long)(bal & lanes_below(c.lane)))] = (uint16_t)x;
+            nxl += __popcll((unsigned long long)bal);
+        }
         __syncthreads();
         for (int base = 0; base < L; base += kWave) {
             const int j = base + c.lane;
@@ -993,33 +1028,54 @@ __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, float *obs, uint
                 pw2 = c.phi[rec_mod<R32>(a, b)] * w2;
             }
             const int tile_n = min(kWave, L - base);
-            for (int x0 = 0; x0 < nx; x0 += kWave) {
-                const int x = x0 + c.lane;
+            // all interferers of the tile inside the pair table? (always, unless a replayed trace carries a bit rate
+            // beyond the configured ones) -> branch-free inner loop with 4 gathers in flight
+            const bool all_tab = __ballot(j < L && nk > P.tab_nmax) == 0;
+            const auto *tab = G(reinterpret_cast<const double *>(P.pair_tab));
+            for (int x0 = 0; x0 < nxl; x0 += kWave) {
+                const bool live = x0 + c.lane < nxl;
+                const int x = live ? xlist[x0 + c.lane] : 0;
                 double f = 0.0;
-                for (int t = 0; t < tile_n; t++) {
-                    const int cc = __builtin_amdgcn_readlane(c2k, t), nn = __builtin_amdgcn_readlane(nk, t);
-                    const double w1t = readlane_f64(w1, t), pw2t = readlane_f64(pw2, t);
-                    const int adi = abs(x - cc);
-                    if (adi > nn) {   // |df| > Bk/2; positions overlapping the interferer are never valid starts
-                        double A, R;
-                        if (nn <= P.tab_nmax) {
-                            const auto *tb = G(reinterpret_cast<const double *>(P.pair_tab)) + 2 * ((nn - 1) * P.tab_stride + adi);
-                            A = tb[0]; R = tb[1];
-                        } else {
-                            double bk = P.slot_bw * nn, adf = (0.5 * P.slot_bw) * (double)adi, ck = P.alpha0_cl * bk;
-                            A = asinh_diff(ck * (adf + 0.5 * bk), ck * (adf - 0.5 * bk));
-                            R = bk / adf;
+                if (all_tab) {
+                    for (int t = 0; t < tile_n; t += 4) {
+                        int off[4]; double w1t[4], pw2t[4]; bool ok[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int tt = min(t + u, tile_n - 1);
+                            const int cc = __builtin_amdgcn_readlane(c2k, tt), nn = __builtin_amdgcn_readlane(nk, tt);
+                            w1t[u] = readlane_f64(w1, tt); pw2t[u] = readlane_f64(pw2, tt);
+                            const int adi = abs(x - cc);
+                            ok[u] = (t + u < tile_n) && adi > nn && adi < P.tab_stride;   // |df| > Bk/2, inside the band
+                            off[u] = ok[u] ? 2 * ((nn - 1) * P.tab_stride + adi) : 0;
                         }
-                        f += A * w1t - R * pw2t;
+                        double A[4], R[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { A[u] = tab[off[u]]; R[u] = tab[off[u] + 1]; }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) if (ok[u]) f += A[u] * w1t[u] - R[u] * pw2t[u];
+                    }
+                } else {
+                    for (int t = 0; t < tile_n; t++) {
+                        const int cc = __builtin_amdgcn_readlane(c2k, t), nn = __builtin_amdgcn_readlane(nk, t);
+                        const double w1t = readlane_f64(w1, t), pw2t = readlane_f64(pw2, t);
+                        const int adi = abs(x - cc);
+                        if (adi > nn) {   // |df| > Bk/2; positions overlapping the interferer are never valid starts
+                            double A, R;
+                            if (nn <= P.tab_nmax) { A = tab[2 * ((nn - 1) * P.tab_stride + adi)]; R = tab[2 * ((nn - 1) * P.tab_stride + adi) + 1]; }
+                            else {
+                                double bk = P.slot_bw * nn, adf = (0.5 * P.slot_bw) * (double)adi, ck = P.alpha0_cl * bk;
+                                A = asinh_diff(ck * (adf + 0.5 * bk), ck * (adf - 0.5 * bk));
+                                R = bk / adf;
+                            }
+                            f += A * w1t - R * pw2t;
+                        }
                     }
                 }
-                if (x < nx) Fx[x] += f;
+                if (live) Fx[x] += f;
             }
         }
         __syncthreads();
         // ---- per modulation, best first (mod_list = reversed(modulations[0:M]), :716-717)
-        uint64_t runs = free_ext;
-        int r = 1;
         const double pw1 = G(P.path_w1)[path], pase = G(P.path_ase)[path];
         for (int mi = 0; mi < M; mi++) {
             const int m = M - 1 - mi;
@@ -1031,14 +1087,12 @@ __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, float *obs, uint
                 for (int i = c.lane; i < S; i += kWave) mm[i] = 0;
                 continue;
             }
-            if (n + 1 < r) { runs = free_ext; r = 1; }
-            runs = run_and(runs, r, n + 1);                              // valid starts of _get_candidates (:590)
             const double thr = P.mod_thr[m], bw = P.slot_bw * n;
             const double self = pw1 * G(P.self_asinh)[n], nlic = G(P.nli_coef)[n] * c.rp[1];
             int cnt_l = 0, sum_l = 0, sum2_l = 0, max_l = 0;
             double os_l = 0.0, os2_l = 0.0, omax_l = -1e300;
             for (int i = 0; i < W; i++) {
-                const uint64_t w = readlane_u64(runs, i);
+                const uint64_t w = Vw[mi * kMaxRowWords + i];   // valid starts of _get_candidates (:590)
                 const int s = i * 64 + c.lane;
                 const bool valid = ((w >> c.lane) & 1ull) && s < S;
                 uint8_t bit = 0;

@@ -111,7 +111,11 @@ __global__ __launch_bounds__(64) void k_observe(const Params *__restrict__ Pp, f
     double *Fx = reinterpret_cast<double *>(smem + lds_bytes(P.n_links, P.row_words, P.capacity, P.uniform_alpha));
     const size_t obs_dim = 3 + P.k_paths + (size_t)P.k_paths * P.n_mods * 12;
     const size_t nact = (size_t)P.k_paths * P.n_mods * P.n_slots + 1;
-    observe_env<R32>(c, Fx, obs + (size_t)c.replica * obs_dim, mask + (size_t)c.replica * nact);
+    // extra LDS of the observation kernel: Fx f64[2S+2] | Vw u64[8*16] | xlist u16[2S+2] | needx u8[2S+2]
+    uint64_t *Vw = reinterpret_cast<uint64_t *>(Fx + 2 * P.n_slots + 2);
+    uint16_t *xlist = reinterpret_cast<uint16_t *>(Vw + kMaxMods * kMaxRowWords);
+    uint8_t *needx = reinterpret_cast<uint8_t *>(xlist + 2 * P.n_slots + 2);
+    observe_env<R32>(c, Fx, Vw, xlist, needx, obs + (size_t)c.replica * obs_dim, mask + (size_t)c.replica * nact);
 }
 
 __global__ void k_seed(Params P, uint64_t seed) {
@@ -714,7 +718,7 @@ int ongym_observe(ongym_env *env, float *obs, uint8_t *mask) {
     const size_t obs_dim = 3 + P.k_paths + (size_t)P.k_paths * P.n_mods * 12;
     const size_t nact = (size_t)P.k_paths * P.n_mods * P.n_slots + 1;
     const size_t B = (size_t)P.batch;
-    const size_t lds = env->lds + ((size_t)2 * P.n_slots + 2) * sizeof(double);
+    const size_t lds = ((env->lds + ((size_t)2 * P.n_slots + 2) * (sizeof(double) + 2 + 1) + kMaxMods * kMaxRowWords * 8) + 15) & ~(size_t)15;
     if (lds > 64 * 1024) {
         HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_observe<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_observe<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
