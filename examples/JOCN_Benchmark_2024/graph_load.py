@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Load sweep of the JOCN benchmark (reference: examples/JOCN_Benchmark_2024/graph_load.py), batched: all loads x R
-parallel simulations are replicas of ONE device environment; heuristics 1 (first fit) and 4 (load balancing best
-modulation) are fused on device.
+parallel simulations are replicas of ONE device environment; heuristics 1 (first fit), 2 (highest SNR) and
+4 (load balancing best modulation) are fused on device.
 
     python examples/JOCN_Benchmark_2024/graph_load.py -t nobel-eu.xml -e 1000 -s 1000
 """
@@ -27,8 +27,8 @@ def main():
     ap.add_argument("-e", "--num_episodes", type=int, default=25)
     ap.add_argument("-s", "--episode_length", type=int, default=1000)
     ap.add_argument("-th", "--threads", type=int, default=25, help="parallel simulations (replicas) per load")
-    ap.add_argument("-hi", "--heuristic_index", type=int, default=1, choices=[1, 4],
-                    help="1: first fit, 4: load balancing best modulation (the two heuristics fused on device)")
+    ap.add_argument("-hi", "--heuristic_index", type=int, default=1, choices=[1, 2, 4],
+                    help="1: first fit, 2: highest SNR, 4: load balancing best modulation (fused on device)")
     ap.add_argument("-mf", "--monitor_file_name", default="examples/JOCN_Benchmark_2024/results/load_episodes")
     ap.add_argument("--launch_power", type=float, default=1.0)
     ap.add_argument("--seed", type=int, default=50)
@@ -43,7 +43,7 @@ def main():
     res = run_sweep(topology, n_episodes=args.num_episodes, episode_length=args.episode_length,
                     replicas_per_point=min(args.threads, args.num_episodes), seed=args.seed, common=common,
                     points=[dict(load=float(ld)) for ld in loads], monitor_names=names,
-                    policy={1: 0, 4: 1}[args.heuristic_index])
+                    policy={1: 0, 2: 2, 4: 1}[args.heuristic_index])
     for ld, b in zip(loads, res):
         print(f"Load: {ld} Erlang, episode_service_blocking_rate mean: {b.mean():.4f}")
 

@@ -38,7 +38,9 @@ enum {
 /* policies fused on device; replaces optical_networking_gym/heuristics/heuristics.py:923-966 */
 enum {
     ONGYM_POLICY_FIRST_FIT = 0,      /* heuristic_shortest_available_path_first_fit_best_modulation, heuristics.py:923-966 */
-    ONGYM_POLICY_LOAD_BALANCING = 1  /* load_balancing_best_modulation, heuristics.py:547-627 (graph_load.py heuristic 4) */
+    ONGYM_POLICY_LOAD_BALANCING = 1, /* load_balancing_best_modulation, heuristics.py:547-627 (graph_load.py heuristic 4) */
+    ONGYM_POLICY_HIGHEST_SNR = 2     /* heuristic_highest_snr, heuristics.py:272-328 (graph_load.py heuristic 2); needs
+                                        uniform attenuation */
 };
 
 /* ongym_step_rec.flags */

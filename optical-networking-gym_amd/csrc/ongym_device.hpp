@@ -120,6 +120,9 @@ __host__ __device__ inline size_t lds_bytes(int n_links, int row_words, int capa
 #define STAMP(c, idx) do { } while (0)
 #endif
 
+// extra LDS of the kernels that evaluate EVERY candidate of a path (observation, highest-SNR policy)
+struct FieldLds { double *Fx; uint64_t *Vw; uint16_t *xlist; uint8_t *needx; };
+
 struct Ctx {
 #ifdef ONGYM_STAMPS
     unsigned long long stamp_acc[ONGYM_NSTAMPS];
@@ -133,6 +136,7 @@ struct Ctx {
     DevEnv *e;
     uint32_t *sa, *sb;
     float *sr;
+    FieldLds fl;       // valid only in k_observe and the highest-SNR variant of k_run
     int *nreq;
     double *lim;       // LDS [8] linear-domain acceptance limits 10^(-(thr_m+margin)/10) of this replica
     double *rp;        // LDS [2] 1/launch_power, launch_power^2 of this replica
@@ -615,6 +619,7 @@ __device__ __forceinline__ void policy_load_balancing(Ctx &c, int src, int dst, 
     ch.flags = (any_res ? ONGYM_F_BLOCKED_RESOURCES : 0) | (any_osnr ? ONGYM_F_BLOCKED_OSNR : 0);
 }
 
+
 // ---- decode + validate an external action (envs/qrmsa.pyx:801-834, 867-909) ------------------------------------
 // returns 0 accept (GN evaluated, passes), 1 reject action, 2 slots not free (retry), 3 QoT infeasible
 template <bool UNIFORM_ALPHA, bool R32>
@@ -919,6 +924,123 @@ __device__ __forceinline__ double wave_max_f64(double v) {
     return v;
 }
 
+
+// Field builder shared by the observation kernel and the highest-SNR policy. For path `p` (free bitmap `free_ext`):
+//   Vw[mi*16 + w] : valid starts of modulation mi (best first) as run-AND words
+//   Fx[x]         : interferer part of the NLI sum for a candidate centred at half-slot x, at every x = 2s + n that some
+//                   valid (modulation, start) pair produces (0 elsewhere)
+
+template <bool R32>
+__device__ __forceinline__ void build_field(Ctx &c, const PathRef &p, uint64_t free_ext, const FieldLds &fl) {
+    const Params &P = c.P;
+    const int M = P.n_mods, S = P.n_slots, nx = 2 * S + 1, W = P.row_words;
+    double *Fx = fl.Fx; uint64_t *Vw = fl.Vw; uint16_t *xlist = fl.xlist; uint8_t *needx = fl.needx;
+    const int L = gn_build_list<R32>(c, p.m0, p.m1);
+    // valid starts of every modulation (run-AND words, lane w = word w) and the candidate centres x = 2s + n they
+    // produce: the field is only needed there (a loaded network has few valid starts)
+    for (int x = c.lane; x < nx + 1; x += kWave) { Fx[x] = 0.0; needx[x] = 0; }
+    {
+        uint64_t runs0 = free_ext;
+        int r0 = 1;
+        for (int mi = 0; mi < M; mi++) {
+            const int n = uniform_i32(c.nreq[M - 1 - mi]);
+            uint64_t v = 0;
+            if (n > 0 && n <= S) {
+                if (n + 1 < r0) { runs0 = free_ext; r0 = 1; }
+                runs0 = run_and(runs0, r0, n + 1);
+                v = runs0;
+            }
+            if (c.lane < kMaxRowWords) Vw[mi * kMaxRowWords + c.lane] = v;
+        }
+    }
+    __syncthreads();
+    for (int mi = 0; mi < M; mi++) {
+        const int n = uniform_i32(c.nreq[M - 1 - mi]);
+        for (int i = 0; i < W; i++) {
+            const uint64_t w = Vw[mi * kMaxRowWords + i];
+            const int sl = i * 64 + c.lane;
+            if (((w >> c.lane) & 1ull) && sl < S) needx[2 * sl + n] = 1;
+        }
+    }
+    __syncthreads();
+    int nxl = 0;
+    for (int x0 = 0; x0 < nx; x0 += kWave) {
+        const int x = x0 + c.lane;
+        const bool need = x < nx && needx[x];
+        const uint64_t bal = __ballot(need);
+        if (need) xlist[nxl + __popcll((unsigned long long)(bal & lanes_below(c.lane)))] = (uint16_t)x;
+        nxl += __popcll((unsigned long long)bal);
+    }
+    __syncthreads();
+    for (int base = 0; base < L; base += kWave) {
+        const int j = base + c.lane;
+        int c2k = 0, nk = 0;
+        double w1 = 0.0, pw2 = 0.0;
+        if (j < L) {
+            const int idx = c.list[j];
+            const uint32_t a = c.sa[idx], b = c.sb[idx];
+            const int sk = rec_slot<R32>(a, b);
+            nk = rec_n<R32>(a, b);
+            c2k = 2 * sk + nk;
+            uint64_t m0, m1;
+            if (R32) { m0 = a & (uint32_t)p.m0; m1 = 0; }
+            else { int pk = a & 0xFFFF; m0 = G(P.path_mask)[2 * pk] & p.m0; m1 = G(P.path_mask)[2 * pk + 1] & p.m1; }
+            double w2 = 0.0;
+            while (m0) { int l = __ffsll((unsigned long long)m0) - 1; m0 &= m0 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
+            while (m1) { int l = 64 + __ffsll((unsigned long long)m1) - 1; m1 &= m1 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
+            pw2 = c.phi[rec_mod<R32>(a, b)] * w2;
+        }
+        const int tile_n = min(kWave, L - base);
+        // all interferers of the tile inside the pair table? (always, unless a replayed trace carries a bit rate
+        // beyond the configured ones) -> branch-free inner loop with 4 gathers in flight
+        const bool all_tab = __ballot(j < L && nk > P.tab_nmax) == 0;
+        const auto *tab = G(reinterpret_cast<const double *>(P.pair_tab));
+        for (int x0 = 0; x0 < nxl; x0 += kWave) {
+            const bool live = x0 + c.lane < nxl;
+            const int x = live ? xlist[x0 + c.lane] : 0;
+            double f = 0.0;
+            if (all_tab) {
+                for (int t = 0; t < tile_n; t += 4) {
+                    int off[4]; double w1t[4], pw2t[4]; bool ok[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int tt = min(t + u, tile_n - 1);
+                        const int cc = __builtin_amdgcn_readlane(c2k, tt), nn = __builtin_amdgcn_readlane(nk, tt);
+                        w1t[u] = readlane_f64(w1, tt); pw2t[u] = readlane_f64(pw2, tt);
+                        const int adi = abs(x - cc);
+                        ok[u] = (t + u < tile_n) && adi > nn && adi < P.tab_stride;   // |df| > Bk/2, inside the band
+                        off[u] = ok[u] ? 2 * ((nn - 1) * P.tab_stride + adi) : 0;
+                    }
+                    double A[4], R[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { A[u] = tab[off[u]]; R[u] = tab[off[u] + 1]; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) if (ok[u]) f += A[u] * w1t[u] - R[u] * pw2t[u];
+                }
+            } else {
+                for (int t = 0; t < tile_n; t++) {
+                    const int cc = __builtin_amdgcn_readlane(c2k, t), nn = __builtin_amdgcn_readlane(nk, t);
+                    const double w1t = readlane_f64(w1, t), pw2t = readlane_f64(pw2, t);
+                    const int adi = abs(x - cc);
+                    if (adi > nn) {   // |df| > Bk/2; positions overlapping the interferer are never valid starts
+                        double A, R;
+                        if (nn <= P.tab_nmax) { A = tab[2 * ((nn - 1) * P.tab_stride + adi)]; R = tab[2 * ((nn - 1) * P.tab_stride + adi) + 1]; }
+                        else {
+                            double bk = P.slot_bw * nn, adf = (0.5 * P.slot_bw) * (double)adi, ck = P.alpha0_cl * bk;
+                            A = asinh_diff(ck * (adf + 0.5 * bk), ck * (adf - 0.5 * bk));
+                            R = bk / adf;
+                        }
+                        f += A * w1t - R * pw2t;
+                    }
+                }
+            }
+            if (live) Fx[x] += f;
+        }
+    }
+    __syncthreads();
+    __syncthreads();
+}
+
 template <bool R32>
 __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, uint16_t *xlist, uint8_t *needx,
                                             float *obs, uint8_t *mask) {
@@ -971,110 +1093,8 @@ __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, ui
         }
         const int nb = wave_sum_i32(nb_l);
         const double len2 = (double)wave_sum_i32(len2_l);
-        // ---- interferer field F(x)
-        const int L = gn_build_list<R32>(c, p.m0, p.m1);
-        // valid starts of every modulation (run-AND words, lane w = word w) and the candidate centres x = 2s + n they
-        // produce: the field is only needed there (a loaded network has few valid starts)
-        for (int x = c.lane; x < nx + 1; x += kWave) { Fx[x] = 0.0; needx[x] = 0; }
-        {
-            uint64_t runs0 = free_ext;
-            int r0 = 1;
-            for (int mi = 0; mi < M; mi++) {
-                const int n = uniform_i32(c.nreq[M - 1 - mi]);
-                uint64_t v = 0;
-                if (n > 0 && n <= S) {
-                    if (n + 1 < r0) { runs0 = free_ext; r0 = 1; }
-                    runs0 = run_and(runs0, r0, n + 1);
-                    v = runs0;
-                }
-                if (c.lane < kMaxRowWords) Vw[mi * kMaxRowWords + c.lane] = v;
-            }
-        }
-        __syncthreads();
-        for (int mi = 0; mi < M; mi++) {
-            const int n = uniform_i32(c.nreq[M - 1 - mi]);
-            for (int i = 0; i < W; i++) {
-                const uint64_t w = Vw[mi * kMaxRowWords + i];
-                const int sl = i * 64 + c.lane;
-                if (((w >> c.lane) & 1ull) && sl < S) needx[2 * sl + n] = 1;
-            }
-        }
-        __syncthreads();
-        int nxl = 0;
-        for (int x0 = 0; x0 < nx; x0 += kWave) {
-            const int x = x0 + c.lane;
-            const bool need = x < nx && needx[x];
-            const uint64_t bal = __ballot(need);
-            if (need) xlist[nxl + __popcll((unsigned long long)(bal & lanes_below(c.lane)))] = (uint16_t)x;
-            nxl += __popcll((unsigned long long)bal);
-        }
-        __syncthreads();
-        for (int base = 0; base < L; base += kWave) {
-            const int j = base + c.lane;
-            int c2k = 0, nk = 0;
-            double w1 = 0.0, pw2 = 0.0;
-            if (j < L) {
-                const int idx = c.list[j];
-                const uint32_t a = c.sa[idx], b = c.sb[idx];
-                const int sk = rec_slot<R32>(a, b);
-                nk = rec_n<R32>(a, b);
-                c2k = 2 * sk + nk;
-                uint64_t m0, m1;
-                if (R32) { m0 = a & (uint32_t)p.m0; m1 = 0; }
-                else { int pk = a & 0xFFFF; m0 = G(P.path_mask)[2 * pk] & p.m0; m1 = G(P.path_mask)[2 * pk + 1] & p.m1; }
-                double w2 = 0.0;
-                while (m0) { int l = __ffsll((unsigned long long)m0) - 1; m0 &= m0 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
-                while (m1) { int l = 64 + __ffsll((unsigned long long)m1) - 1; m1 &= m1 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
-                pw2 = c.phi[rec_mod<R32>(a, b)] * w2;
-            }
-            const int tile_n = min(kWave, L - base);
-            // all interferers of the tile inside the pair table? (always, unless a replayed trace carries a bit rate
-            // beyond the configured ones) -> branch-free inner loop with 4 gathers in flight
-            const bool all_tab = __ballot(j < L && nk > P.tab_nmax) == 0;
-            const auto *tab = G(reinterpret_cast<const double *>(P.pair_tab));
-            for (int x0 = 0; x0 < nxl; x0 += kWave) {
-                const bool live = x0 + c.lane < nxl;
-                const int x = live ? xlist[x0 + c.lane] : 0;
-                double f = 0.0;
-                if (all_tab) {
-                    for (int t = 0; t < tile_n; t += 4) {
-                        int off[4]; double w1t[4], pw2t[4]; bool ok[4];
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            const int tt = min(t + u, tile_n - 1);
-                            const int cc = __builtin_amdgcn_readlane(c2k, tt), nn = __builtin_amdgcn_readlane(nk, tt);
-                            w1t[u] = readlane_f64(w1, tt); pw2t[u] = readlane_f64(pw2, tt);
-                            const int adi = abs(x - cc);
-                            ok[u] = (t + u < tile_n) && adi > nn && adi < P.tab_stride;   // |df| > Bk/2, inside the band
-                            off[u] = ok[u] ? 2 * ((nn - 1) * P.tab_stride + adi) : 0;
-                        }
-                        double A[4], R[4];
-#pragma unroll
-                        for (int u = 0; u < 4; u++) { A[u] = tab[off[u]]; R[u] = tab[off[u] + 1]; }
-#pragma unroll
-                        for (int u = 0; u < 4; u++) if (ok[u]) f += A[u] * w1t[u] - R[u] * pw2t[u];
-                    }
-                } else {
-                    for (int t = 0; t < tile_n; t++) {
-                        const int cc = __builtin_amdgcn_readlane(c2k, t), nn = __builtin_amdgcn_readlane(nk, t);
-                        const double w1t = readlane_f64(w1, t), pw2t = readlane_f64(pw2, t);
-                        const int adi = abs(x - cc);
-                        if (adi > nn) {   // |df| > Bk/2; positions overlapping the interferer are never valid starts
-                            double A, R;
-                            if (nn <= P.tab_nmax) { A = tab[2 * ((nn - 1) * P.tab_stride + adi)]; R = tab[2 * ((nn - 1) * P.tab_stride + adi) + 1]; }
-                            else {
-                                double bk = P.slot_bw * nn, adf = (0.5 * P.slot_bw) * (double)adi, ck = P.alpha0_cl * bk;
-                                A = asinh_diff(ck * (adf + 0.5 * bk), ck * (adf - 0.5 * bk));
-                                R = bk / adf;
-                            }
-                            f += A * w1t - R * pw2t;
-                        }
-                    }
-                }
-                if (live) Fx[x] += f;
-            }
-        }
-        __syncthreads();
+        // ---- interferer field F(x) at the needed centres + valid starts per modulation (shared builder)
+        build_field<R32>(c, p, free_ext, FieldLds{Fx, Vw, xlist, needx});
         // ---- per modulation, best first (mod_list = reversed(modulations[0:M]), :716-717)
         const double pw1 = G(P.path_w1)[path], pase = G(P.path_ase)[path];
         for (int mi = 0; mi < M; mi++) {
@@ -1143,6 +1163,82 @@ __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, ui
             }
         }
     }
+}
+
+// ---- heuristic_highest_snr (heuristics/heuristics.py:272-328) ---------------------------------------------------------
+// Every valid start of every (path, modulation) pair is evaluated (one LDS read of the path's interferer field per
+// candidate); among those that clear threshold + margin the highest GSNR wins, first one in (path, modulation best
+// first, slot ascending) order on ties — the reference's strict `osnr > best_osnr`.
+template <bool R32>
+__device__ __forceinline__ void policy_highest_snr(Ctx &c, int src, int dst, double launch_power, double margin, Choice &ch) {
+    const Params &P = c.P;
+    const int M = P.n_mods, S = P.n_slots, max_mod = M - 1, W = P.row_words;
+    ch.action = P.k_paths * M * S; ch.route = -1; ch.mod = -1; ch.slot = -1; ch.n = 0; ch.hops = 0; ch.mylink = 0;
+    ch.path = -1; ch.m0 = 0; ch.g.ase = ch.g.nli = 0.0; ch.flags = 0;
+    int any_res = 0, any_osnr = 0;
+    double best_osnr = -INFINITY;
+    for (int k = 0; k < P.k_paths; k++) {
+        int path = k == 0 ? c.pre_id : G(P.pair_paths)[(src * P.n_nodes + dst) * P.k_paths + k];
+        if (path < 0) break;
+        PathRef p;
+        if (k == 0) { p.id = path; p.hops = c.pre_hops; p.mylink = c.pre_mylink; p.m0 = c.pre_m0; p.m1 = c.pre_m1; }
+        else p = load_path(c, path);
+        c.paths_tried++; c.path_hops += p.hops;
+        const uint64_t free_ext = path_free_ext(c, p);
+        build_field<R32>(c, p, free_ext, c.fl);
+        const double pw1 = G(P.path_w1)[path], pase = G(P.path_ase)[path];
+        for (int m = max_mod; m >= 0; m--) {
+            const int mi = max_mod - m;
+            const int n = uniform_i32(c.nreq[m]);
+            if (n <= 0) continue;
+            const double thr = P.mod_thr[m] + margin, lim = c.lim[m], bw = P.slot_bw * n;
+            const double self = pw1 * G(P.self_asinh)[n], nlic = G(P.nli_coef)[n] * c.rp[1];
+            int nvalid = 0;
+            for (int i = 0; i < W; i++) {
+                const uint64_t w = c.fl.Vw[mi * kMaxRowWords + i];
+                if (!w) continue;
+                const int s = i * 64 + c.lane;
+                const bool valid = ((w >> c.lane) & 1ull) && s < S;
+                nvalid += __popcll((unsigned long long)w);
+                double v = -INFINITY;
+                bool fail = false;
+                if (valid) {
+                    const double fc = P.f0 + (P.slot_bw * s) + (P.slot_bw * (n / 2.0));
+                    const double acc = (bw * fc * pase) * c.rp[0] + nlic * (self + c.fl.Fx[2 * s + n]);
+                    const double osnr = -10.0 * log10(acc);
+                    bool ok;
+                    if (acc <= lim * (1.0 - 1e-9)) ok = true;
+                    else if (acc >= lim * (1.0 + 1e-9)) ok = false;
+                    else ok = 10.0 * log10(1.0 / acc) >= thr;
+                    if (ok) v = osnr; else fail = true;
+                }
+                if (__ballot(fail)) any_osnr = 1;
+                const double vmax = wave_max_f64(v);
+                if (vmax > best_osnr) {                                   // strict: the first maximum wins
+                    const uint64_t bal = __ballot(v == vmax);
+                    const int ln = __ffsll((unsigned long long)bal) - 1;
+                    best_osnr = vmax;
+                    ch.route = k; ch.mod = m; ch.slot = i * 64 + ln; ch.n = n; ch.path = path;
+                }
+            }
+            if (nvalid == 0) any_res = 1;
+            c.gn_evals += nvalid;
+        }
+    }
+    if (ch.route < 0) {
+        if (any_osnr) any_res = 0;
+        ch.flags = (any_res ? ONGYM_F_BLOCKED_RESOURCES : 0) | (any_osnr ? ONGYM_F_BLOCKED_OSNR : 0);
+        return;
+    }
+    // the winner's ASE / NLI split and path registers (same evaluation as the other policies)
+    PathRef p = load_path(c, ch.path);
+    ch.hops = p.hops; ch.mylink = p.mylink; ch.m0 = p.m0;
+    ch.action = ch.route * M * S + (max_mod - ch.mod) * S + ch.slot;
+    const int L = gn_build_list<R32>(c, p.m0, p.m1);
+    GnLin g = gn_eval<true, R32>(c, p, L, ch.slot, ch.n);
+    c.gn_evals--;   // not a candidate evaluation of the heuristic
+    ch.g.ase = uniform_f64(g.ase); ch.g.nli = uniform_f64(g.nli);
+    (void)launch_power;
 }
 
 __device__ __forceinline__ void load_state(Ctx &c) {

@@ -35,6 +35,12 @@ __global__ __launch_bounds__(64, WAVES) void k_run(const Params *__restrict__ Pp
     for (int i = 0; i < ONGYM_NSTAMPS; i++) c.stamp_acc[i] = 0;
     c.stamp_last = __builtin_amdgcn_s_memtime();
 #endif
+    if (POLICY == ONGYM_POLICY_HIGHEST_SNR) {   // extra LDS: Fx f64[2S+2] | Vw u64[8*16] | xlist u16[2S+2] | needx u8[2S+2]
+        c.fl.Fx = reinterpret_cast<double *>(smem + lds_bytes(P.n_links, P.row_words, P.capacity, P.uniform_alpha));
+        c.fl.Vw = reinterpret_cast<uint64_t *>(c.fl.Fx + 2 * P.n_slots + 2);
+        c.fl.xlist = reinterpret_cast<uint16_t *>(c.fl.Vw + kMaxMods * kMaxRowWords);
+        c.fl.needx = reinterpret_cast<uint8_t *>(c.fl.xlist + 2 * P.n_slots + 2);
+    }
     load_state(c);
     STAMP(c, 8);
     for (int it = 0; it < nsteps; ++it) {
@@ -60,7 +66,8 @@ __global__ __launch_bounds__(64, WAVES) void k_run(const Params *__restrict__ Pp
         if (mode == kModeActionStep) {
             outcome = evaluate_action<UA, R32>(c, src, dst, lp, mg, actions[c.replica], ch);
         } else {
-            if (POLICY == ONGYM_POLICY_LOAD_BALANCING) policy_load_balancing<UA, R32>(c, src, dst, lp, mg, ch);
+            if (POLICY == ONGYM_POLICY_HIGHEST_SNR) policy_highest_snr<R32>(c, src, dst, lp, mg, ch);
+            else if (POLICY == ONGYM_POLICY_LOAD_BALANCING) policy_load_balancing<UA, R32>(c, src, dst, lp, mg, ch);
             else policy_first_fit<UA, R32>(c, src, dst, lp, mg, ch);
             outcome = ch.route >= 0 ? 0 : 1;
         }
@@ -115,6 +122,7 @@ __global__ __launch_bounds__(64) void k_observe(const Params *__restrict__ Pp, f
     uint64_t *Vw = reinterpret_cast<uint64_t *>(Fx + 2 * P.n_slots + 2);
     uint16_t *xlist = reinterpret_cast<uint16_t *>(Vw + kMaxMods * kMaxRowWords);
     uint8_t *needx = reinterpret_cast<uint8_t *>(xlist + 2 * P.n_slots + 2);
+    c.fl = FieldLds{Fx, Vw, xlist, needx};
     observe_env<R32>(c, Fx, Vw, xlist, needx, obs + (size_t)c.replica * obs_dim, mask + (size_t)c.replica * nact);
 }
 
@@ -641,13 +649,28 @@ int ongym_reset(ongym_env *env, const uint8_t *mask) {
     return ONGYM_OK;
 }
 
+static size_t field_lds(const ongym_env *env) {   // k_observe / highest-SNR k_run: state block + Fx, Vw, xlist, needx
+    const Params &P = env->P;
+    return ((env->lds + ((size_t)2 * P.n_slots + 2) * (sizeof(double) + 2 + 1) + kMaxMods * kMaxRowWords * 8) + 15) & ~(size_t)15;
+}
+
 static int launch_run(ongym_env *env, int mode, int policy, int nsteps, const int32_t *d_actions, int32_t *d_act_out,
                       uint8_t *d_flag_out, ongym_step_rec *d_out) {
     HIP_TRY(env, hipEventRecord(env->ev0, env->stream));
     const dim3 grid(env->P.batch), block(64);
+    if (policy == ONGYM_POLICY_HIGHEST_SNR) {
+        if (!env->P.uniform_alpha) return fail_arg(env, "the highest-SNR policy needs uniform attenuation", ONGYM_E_LIMIT);
+        if (field_lds(env) > 64 * 1024) {
+            HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_run<true, true, 4, ONGYM_POLICY_HIGHEST_SNR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)field_lds(env)));
+            HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_run<true, false, 4, ONGYM_POLICY_HIGHEST_SNR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)field_lds(env)));
+        }
+    }
 #define ONGYM_LAUNCH_RUN(UA, R)                                                                                    \
     do {                                                                                                           \
-        if (policy == ONGYM_POLICY_LOAD_BALANCING)                                                                 \
+        if (policy == ONGYM_POLICY_HIGHEST_SNR)                                                                    \
+            hipLaunchKernelGGL((k_run<true, R, 4, ONGYM_POLICY_HIGHEST_SNR>), grid, block, field_lds(env),          \
+                               env->stream, env->d_P, mode, nsteps, d_actions, d_act_out, d_flag_out, d_out);      \
+        else if (policy == ONGYM_POLICY_LOAD_BALANCING)                                                            \
             hipLaunchKernelGGL((k_run<UA, R, 4, ONGYM_POLICY_LOAD_BALANCING>), grid, block, env->lds, env->stream,  \
                                env->d_P, mode, nsteps, d_actions, d_act_out, d_flag_out, d_out);                   \
         else if (env->lds <= 8192)                                                                                 \
@@ -676,7 +699,7 @@ static int ensure_out(ongym_env *env, size_t n) {
 
 int ongym_step_policy(ongym_env *env, int32_t policy, int32_t nsteps, ongym_step_rec *out) {
     if (!env) return ONGYM_E_ARG;
-    if (policy != ONGYM_POLICY_FIRST_FIT && policy != ONGYM_POLICY_LOAD_BALANCING) return fail_arg(env, "unknown policy id");
+    if (policy < ONGYM_POLICY_FIRST_FIT || policy > ONGYM_POLICY_HIGHEST_SNR) return fail_arg(env, "unknown policy id");
     if (nsteps <= 0) return fail_arg(env, "nsteps must be positive");
     if (!env->has_source) { env->err = "no request source: call ongym_seed or ongym_set_requests first"; return ONGYM_E_STATE; }
     HIP_TRY(env, hipSetDevice(env->cfg.device));
@@ -718,7 +741,7 @@ int ongym_observe(ongym_env *env, float *obs, uint8_t *mask) {
     const size_t obs_dim = 3 + P.k_paths + (size_t)P.k_paths * P.n_mods * 12;
     const size_t nact = (size_t)P.k_paths * P.n_mods * P.n_slots + 1;
     const size_t B = (size_t)P.batch;
-    const size_t lds = ((env->lds + ((size_t)2 * P.n_slots + 2) * (sizeof(double) + 2 + 1) + kMaxMods * kMaxRowWords * 8) + 15) & ~(size_t)15;
+    const size_t lds = field_lds(env);
     if (lds > 64 * 1024) {
         HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_observe<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_observe<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -749,7 +772,7 @@ int ongym_observe(ongym_env *env, float *obs, uint8_t *mask) {
 
 int ongym_policy_actions(ongym_env *env, int32_t policy, int32_t *actions, uint8_t *flags) {
     if (!env || !actions) return env ? fail_arg(env, "null actions") : ONGYM_E_ARG;
-    if (policy != ONGYM_POLICY_FIRST_FIT && policy != ONGYM_POLICY_LOAD_BALANCING) return fail_arg(env, "unknown policy id");
+    if (policy < ONGYM_POLICY_FIRST_FIT || policy > ONGYM_POLICY_HIGHEST_SNR) return fail_arg(env, "unknown policy id");
     HIP_TRY(env, hipSetDevice(env->cfg.device));
     int rc;
     if (env->cfg.io_device) return launch_run(env, kModePolicyOnly, policy, 1, nullptr, actions, flags, nullptr);

@@ -19,6 +19,7 @@ HIP_LIB_PATH = os.path.join(CSRC_DIR, "libongym_hip.so")
 
 POLICY_FIRST_FIT = 0
 POLICY_LOAD_BALANCING = 1
+POLICY_HIGHEST_SNR = 2
 F_BLOCKED_RESOURCES, F_BLOCKED_OSNR, F_QOT_ERROR, F_OVERFLOW, F_NO_REQUEST = 1, 2, 4, 8, 16
 
 _i32p, _f64p = C.POINTER(C.c_int32), C.POINTER(C.c_double)

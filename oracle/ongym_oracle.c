@@ -452,9 +452,46 @@ int orc_policy_load_balancing(orc_env *e, int *blocked_resources, int *blocked_o
     return solution;
 }
 
+/* ---- heuristic_highest_snr (heuristics/heuristics.py:272-328): every valid start of every (path, modulation) --------- */
+int orc_policy_highest_snr(orc_env *e, int *blocked_resources, int *blocked_osnr) {
+    int any_res = 0, any_osnr = 0, have = 0;
+    int S = e->cfg.n_slots, K = e->cfg.k_paths, N = e->cfg.n_nodes;
+    int32_t *avail = e->scratch_avail;
+    int32_t *starts = (int32_t *)malloc(sizeof(int32_t) * (S + 1));
+    int best_action = orc_reject_action(e);
+    double best_osnr = -INFINITY;
+    for (int k = 0; k < K; k++) {
+        int p = e->pair_paths[(e->cur.src * N + e->cur.dst) * K + k];
+        if (p < 0) break;
+        e->total_paths++; e->total_hops += e->path_hops[p];
+        for (int m = e->max_mod_idx; m >= 0; m--) {
+            int req = orc_number_slots(e, e->cur.bit_rate, m);
+            if (req <= 0) continue;
+            orc_available(e, p, avail);
+            int cnt = orc_candidates(avail, S, req, starts, S + 1);
+            if (cnt == 0) { any_res = 1; continue; }
+            for (int i = 0; i < cnt; i++) {
+                double o[3];
+                gn_state(e, p, starts[i], req, o, 1);
+                if (o[0] >= e->mod_thr[m] + e->margin) {
+                    if (o[0] > best_osnr || (o[0] == best_osnr && !have)) {
+                        best_osnr = o[0]; best_action = orc_encode_action(e, k, m, starts[i]); have = 1;
+                    }
+                } else any_osnr = 1;
+            }
+        }
+    }
+    free(starts);
+    if (have) { *blocked_resources = 0; *blocked_osnr = 0; return best_action; }
+    if (any_osnr) any_res = 0;
+    *blocked_resources = any_res; *blocked_osnr = any_osnr;
+    return best_action;
+}
+
 int orc_policy(orc_env *e, int policy, int *bres, int *bosnr) {
-    return policy == ONGYM_POLICY_LOAD_BALANCING ? orc_policy_load_balancing(e, bres, bosnr)
-                                                 : orc_policy_first_fit(e, bres, bosnr);
+    if (policy == ONGYM_POLICY_LOAD_BALANCING) return orc_policy_load_balancing(e, bres, bosnr);
+    if (policy == ONGYM_POLICY_HIGHEST_SNR) return orc_policy_highest_snr(e, bres, bosnr);
+    return orc_policy_first_fit(e, bres, bosnr);
 }
 
 /* ---- reward (envs/qrmsa.pyx:1266-1285): only the not-accepted branch returns a value (quirk Q1) --------------- */

@@ -199,7 +199,8 @@ def run_trajectory(tag, topo_name, seed, load, S, episodes, episode_length=1000,
     finally:
         random.Random = _OrigRandom
     policy_fn = {"first_fit": H.heuristic_shortest_available_path_first_fit_best_modulation,
-                 "load_balancing": H.load_balancing_best_modulation}[policy]
+                 "load_balancing": H.load_balancing_best_modulation,
+                 "highest_snr": H.heuristic_highest_snr}[policy]
     env = wrapper
     reqs, kinds = [], []
     reqs.append(request_tuple(env)); kinds.append(0)   # drawn by the constructor's own reset() (qrmsa.pyx:414-415)
@@ -452,6 +453,10 @@ TRAJ = {
     "traj_nsfnet320_scripted": dict(topo_name="nsfnet", seed=4321, load=300, S=320, episodes=1, scripted=True),
     # load_balancing_best_modulation (heuristics.py:547-627), heuristic 4 of graph_load.py:116-125
     "traj_nsfnet320_lb": dict(topo_name="nsfnet", seed=8, load=500, S=320, episodes=2, policy="load_balancing"),
+    # heuristic_highest_snr (heuristics.py:272-328), heuristic 2 of graph_load.py; small grid: the reference evaluates the
+    # GN model for every valid start of every (path, modulation) pair
+    "traj_nsfnet128_hsnr": dict(topo_name="nsfnet", seed=41, load=120, S=128, episodes=1, episode_length=700,
+                                policy="highest_snr", snap_steps=(100, 400, 650), gn_every=100003),
     "traj_nobeleu320_lb": dict(topo_name="nobel-eu", seed=18, load=700, S=320, episodes=1, policy="load_balancing",
                                launch_power_dbm=1.0),
 }

@@ -283,39 +283,42 @@ def test_full_batch_invariants_nsfnet_4096():
     assert c.stats()["services_accepted"].tobytes() != sa["services_accepted"].tobytes()
 
 
-@pytest.mark.parametrize("tag", ["traj_nsfnet320_lb", "traj_nobeleu320_lb"])
-def test_load_balancing_policy_vs_reference(tag):
-    """fused load_balancing_best_modulation (heuristics.py:547-627) against the reference's captured run."""
+@pytest.mark.parametrize("tag", ["traj_nsfnet320_lb", "traj_nobeleu320_lb", "traj_nsfnet128_hsnr"])
+def test_other_fused_policies_vs_reference(tag):
+    """fused load_balancing_best_modulation (heuristics.py:547-627) / heuristic_highest_snr (:272-328) against the
+    reference's captured runs."""
     meta, d = load_traj(tag)
+    pid = {"load_balancing": nat.POLICY_LOAD_BALANCING, "highest_snr": nat.POLICY_HIGHEST_SNR}[meta["policy"]]
     env = make_env(meta, auto_reset=True)
     env.set_requests(traj_requests(d))
     for _ in range(meta["initial_resets"]):
         env.reset()
-    rec = env.step_policy(meta["n_steps"], policy=nat.POLICY_LOAD_BALANCING)[:, 0]
+    rec = env.step_policy(meta["n_steps"], policy=pid)[:, 0]
     for f, g in (("action", "st_action"), ("accepted", "st_accepted"), ("terminated", "st_term"), ("active", "st_active"),
                  ("route", "st_route"), ("slot", "st_slot"), ("reward", "st_reward")):
         assert np.array_equal(rec[f], d[g]), f
     assert np.array_equal((rec["flags"] & nat.F_BLOCKED_RESOURCES) != 0, d["st_bres"] == 1)
     assert np.array_equal((rec["flags"] & nat.F_BLOCKED_OSNR) != 0, d["st_bosnr"] == 1)
     np.testing.assert_allclose(rec["osnr"], d["st_osnr"], rtol=GSNR_RTOL)
-    assert len(np.unique(rec["route"][rec["accepted"] == 1])) > 1      # the policy does spread over routes
+    assert len(np.unique(rec["route"][rec["accepted"] == 1])) > 1      # both policies do spread over routes
 
 
-def test_load_balancing_policy_vs_oracle_random_traffic():
-    B, steps = 32, 900
-    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=320, batch=B, capacity=1024, load=550,
+@pytest.mark.parametrize("pid,S,load,steps", [(1, 320, 550, 900), (2, 96, 90, 500)])
+def test_other_policies_vs_oracle_random_traffic(pid, S, load, steps):
+    B = 32
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=S, batch=B, capacity=1024, load=load,
               bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), auto_reset=True)
     holder = nat.ConfigHolder(golden_tables("cost239"), **kw)
     want = np.zeros((steps, B), nat.STEP_DTYPE)
     for r in range(B):
         o = OracleEnv(holder, replica=r)
         o.seed(99); o.reset()
-        want[:, r] = o.run_policy(nat.POLICY_LOAD_BALANCING, steps)
+        want[:, r] = o.run_policy(pid, steps)
     env = BatchedQRMSAEnv(tables=golden_tables("cost239"), modulations=jocn_modulations(), batch_size=B,
-                          num_spectrum_resources=320, capacity=1024, load=550, bit_rate_selection="discrete",
+                          num_spectrum_resources=S, capacity=1024, load=load, bit_rate_selection="discrete",
                           bit_rates=(10, 40, 100, 400))
     env.seed(99); env.reset()
-    assert_records_equal(env.step_policy(steps, policy=nat.POLICY_LOAD_BALANCING), want, "load balancing")
-    acts, flags = env.policy_actions(policy=nat.POLICY_LOAD_BALANCING)
+    assert_records_equal(env.step_policy(steps, policy=pid), want, f"policy {pid}")
+    acts, flags = env.policy_actions(policy=pid)
     rec = env.step(acts)
     assert not rec["retry"].any() and not (rec["flags"] & nat.F_QOT_ERROR).any()

@@ -173,16 +173,20 @@ def test_observation_and_mask_vs_reference(tag):
 
 
 # ---- load_balancing_best_modulation (heuristics.py:547-627) -----------------------------------------------------------
-@pytest.mark.parametrize("tag", ["traj_nsfnet320_lb", "traj_nobeleu320_lb"])
-def test_load_balancing_trajectory(tag):
+POLICY_ID = {"first_fit": 0, "load_balancing": 1, "highest_snr": 2}
+
+
+@pytest.mark.parametrize("tag", ["traj_nsfnet320_lb", "traj_nobeleu320_lb", "traj_nsfnet128_hsnr"])
+def test_other_policy_trajectory(tag):
     meta, d = load_traj(tag)
-    assert meta["policy"] == "load_balancing"
+    pid = POLICY_ID[meta["policy"]]
+    assert pid > 0
     env = OracleEnv(holder_for(meta))
     env.set_trace(traj_requests(d))
     for _ in range(meta["initial_resets"]):
         env.reset()
     for i in range(meta["n_steps"]):
-        act, bres, bosnr = env.policy(1)
+        act, bres, bosnr = env.policy(pid)
         assert act == d["st_action"][i], f"step {i}: action {act} != {d['st_action'][i]}"
         assert bres == bool(d["st_bres"][i]) and bosnr == bool(d["st_bosnr"][i]), f"step {i} flags"
         rc, r = env.step(act)
