@@ -322,3 +322,29 @@ def test_other_policies_vs_oracle_random_traffic(pid, S, load, steps):
     acts, flags = env.policy_actions(policy=pid)
     rec = env.step(acts)
     assert not rec["retry"].any() and not (rec["flags"] & nat.F_QOT_ERROR).any()
+
+
+def test_extreme_shapes_vs_oracle(tmp_path):
+    """limits of the kernels: 40-node ring (only 2 of k=5 paths exist per pair, up to 39 hops = 39 lanes per path),
+    S = 1000 slots (16 bitmap words, not a multiple of 64), 1 Tb/s requests (80 slots > one word), 40 links (> 32: generic
+    record codec)."""
+    from optical_networking_gym._tables import StaticTables
+    from optical_networking_gym.topology import get_topology
+    n = 40
+    lines = [str(n), str(n)] + [f"{i + 1} {(i + 1) % n + 1} {150 + 10 * (i % 7)}" for i in range(n)]
+    f = tmp_path / "ring40.txt"
+    f.write_text("\n".join(lines) + "\n")
+    topo = get_topology(str(f), None, jocn_modulations(), 80, 0.2, 4.5, 5)
+    tables = StaticTables.from_topology(topo)
+    assert tables.max_hops == 39 and (tables.pair_paths[:, :, 2:] == -1).all() and tables.n_links == 40
+    B, steps = 8, 500
+    kw = dict(num_spectrum_resources=1000, capacity=1024, load=250, bit_rate_selection="discrete",
+              bit_rates=(10, 100, 400, 1000), episode_length=400)
+    holder = nat.ConfigHolder(tables, modulations=jocn_modulations(), batch=B, auto_reset=True, **kw)
+    want, oracles = run_oracle_batch(holder, 4, steps, B)
+    env = BatchedQRMSAEnv(tables=tables, modulations=jocn_modulations(), batch_size=B, **kw)
+    env.seed(4); env.reset()
+    got = env.step_policy(steps)
+    assert_records_equal(got, want, "ring40/S1000")
+    assert got["nslots"].max() >= 40 and (got["accepted"] == 0).any() and got["slot"].max() > 900
+    np.testing.assert_array_equal(env.grid(3), oracles[3].grid())
