@@ -216,6 +216,9 @@ TOPOLOGY_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "topolog
 
 def bundled_topology_path(name: str) -> str:
     """Path of a topology data file shipped with this package (nsfnet_chen.txt, cost239.txt, nobel-eu.txt, ring_4.txt)."""
+    from ._topology_data import GENERATED, materialize
+    if name in GENERATED:
+        return materialize(name)
     path = os.path.join(TOPOLOGY_DIR, name)
     if not os.path.exists(path):
         raise FileNotFoundError(path)
