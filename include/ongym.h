@@ -75,7 +75,8 @@ typedef struct ongym_config {
     int32_t bit_rate_lo, bit_rate_hi;
     int32_t device;         /* HIP device ordinal */
     int32_t io_device;      /* 1: in/out buffers of step/set_requests calls are device pointers */
-    int32_t reserved0;
+    int32_t measure_disruptions; /* qrmsa.pyx:224, 937-952: after every accept re-evaluate the GSNR of the services that share a
+                                    link with the new one and count those that fall below their modulation's threshold */
     double frequency_start;       /* Hz,  qrmsa.pyx:221 */
     double slot_bandwidth;        /* Hz,  qrmsa.pyx:222 */
     double channel_width;         /* GHz, qrmsa.pyx:228 (get_number_slots, qrmsa.pyx:1198-1205) */
@@ -136,7 +137,7 @@ typedef struct ongym_service {
     int32_t path_id;
     int16_t slot, nslots;
     int16_t modulation;
-    int16_t reserved;
+    int16_t reserved;   /* 1: member of disrupted_services_list (measure_disruptions) */
     float release_time; /* float32(arrival+holding), the heap key after rounding (qrmsa.pyx:1114-1115,1329) */
 } ongym_service;
 
@@ -150,12 +151,14 @@ typedef struct ongym_stats {
     int64_t episode_modulation_hist[8];
     double episode_osnr_sum;                                       /* sum of Service.OSNR over the episode's services */
     int64_t episodes_completed;
+    int64_t disrupted_services, episode_disrupted_services;       /* qrmsa.pyx:948-952 (both zeroed by reset()) */
     /* snapshot taken at the last terminal step (what graph_load.py writes per episode) */
     int64_t last_episode_processed, last_episode_accepted, last_rejected;
     double last_service_blocking_rate, last_episode_service_blocking_rate;
     double last_bit_rate_blocking_rate, last_episode_bit_rate_blocking_rate;
     int64_t last_modulation_hist[8];
     double last_mean_gsnr;
+    int64_t last_episode_disrupted;
     /* totals over all completed steps since create (for throughput accounting and the RCCL stats reduction) */
     int64_t total_steps, total_accepted, total_gn_evals, total_interferer_terms;
     int64_t total_paths_tried, total_path_hops; /* candidate paths whose slot rows were read, and their hops */

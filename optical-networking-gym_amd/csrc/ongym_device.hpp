@@ -56,6 +56,7 @@ struct Params {
     int ext_words;   // Wx = S/64 + 1  : words of the row extended by the virtual free slot S
     int batch, capacity, episode_length, auto_reset;
     int bit_rate_mode, n_bit_rates, br_lo, br_hi;
+    int measure_disruptions;
     int uniform_alpha;
     int rec32;          // record codec R32 in use (n_links <= 32, n_paths <= 512)
     int ase_shortcut;   // 1: every interferer term of the NLI sum is provably >= 0 (checked on the host at create)
@@ -100,11 +101,12 @@ struct Params {
 // ---------------------------------------------------------------------------------------------------------------
 // LDS carve-up (dynamic shared memory), 8-byte aligned pieces first
 //   occ u64[E*W] | lw1 f64[E] | lw2 f64[E] | lcl f64[E] | lsc f64[E] | DevEnv | sa u32[C] | sb u32[C] | sr f32[C] |
-//   lim f64[8] | rp f64[2] | phi f64[8] | nreq i32[8] | list u16[C]
+//   lim f64[8] | rp f64[2] | phi f64[8] | nreq i32[8] | list u16[C] | (lim0 f64[8] when measure_disruptions)
 // ---------------------------------------------------------------------------------------------------------------
-__host__ __device__ inline size_t lds_bytes(int n_links, int row_words, int capacity, int uniform_alpha) {
+__host__ __device__ inline size_t lds_bytes(int n_links, int row_words, int capacity, int uniform_alpha,
+                                            int measure_disruptions = 0) {
     size_t b = (size_t)n_links * row_words * 8 + (size_t)n_links * (uniform_alpha ? 16 : 32) + ((sizeof(DevEnv) + 7) & ~(size_t)7);
-    b += (size_t)capacity * 12 + 64 + 16 + 64 + 32 + (size_t)capacity * 2;
+    b += (size_t)capacity * 12 + 64 + 16 + 64 + 32 + (size_t)capacity * 2 + (measure_disruptions ? 64 : 0);
     return (b + 15) & ~(size_t)15;
 }
 
@@ -140,6 +142,7 @@ struct Ctx {
     int *nreq;
     double *lim;       // LDS [8] linear-domain acceptance limits 10^(-(thr_m+margin)/10) of this replica
     double *rp;        // LDS [2] 1/launch_power, launch_power^2 of this replica
+    double *lim0;      // LDS [8] 10^(-thr_m/10): the disruption check ignores the margin (envs/qrmsa.pyx:947)
     double *phi;       // LDS [8] Phi_mod * 5/3 per modulation
     uint16_t *list;
     double node_cum_reg;   // node_cum[lane] (+inf beyond n_nodes) when n_nodes <= 64
@@ -178,6 +181,7 @@ __device__ __forceinline__ void ctx_bind(Ctx &c, unsigned char *smem) {
     c.phi = c.rp + 2;
     c.nreq = reinterpret_cast<int *>(c.phi + 8);
     c.list = reinterpret_cast<uint16_t *>(c.nreq + 8);
+    c.lim0 = reinterpret_cast<double *>(c.list + P.capacity);   // capacity % 64 == 0 -> 8-byte aligned; only if enabled
 }
 
 // Table pointers live in a Params object read from memory, so the compiler cannot know they are global and would emit
@@ -661,7 +665,7 @@ __device__ __forceinline__ void release_due(Ctx &c, float now) {
     int nchunks = (c.active + kWave - 1) / kWave;
     for (int ch = nchunks - 1; ch >= 0; ch--) {
         int i = ch * kWave + c.lane;
-        float r = (i < c.active) ? c.sr[i] : INFINITY;
+        float r = (i < c.active) ? fabsf(c.sr[i]) : INFINITY;   // sign bit = 'disrupted' flag (measure_disruptions)
         uint64_t bal = __ballot(r <= now);
         while (bal) {
             int ln = 63 - __clzll((unsigned long long)bal);
@@ -783,6 +787,7 @@ __device__ __forceinline__ void reset_env(Ctx &c) {
         s.rejected = 0;
         for (int m = 0; m < 8; m++) s.episode_modulation_hist[m] = 0;
         s.bit_rate_requested = 0.0; s.bit_rate_provisioned = 0.0;   // :466-467
+        s.disrupted_services = 0; s.episode_disrupted_services = 0;   // :432, 468-469
         s.episode_osnr_sum = 0.0;
         e->osnr_flushed = 0.0; c.osnr_prod = 1.0;
         e->have_request = 0;
@@ -806,6 +811,72 @@ __device__ __forceinline__ void snapshot_terminal(DevEnv *e) {   // info of the 
     for (int m = 0; m < 8; m++) s.last_modulation_hist[m] = s.episode_modulation_hist[m];
     // graph_load.py:181-185: mean of Service.OSNR over topology.graph["services"] (one entry per completed step)
     s.last_mean_gsnr = s.episode_services_processed > 0 ? e->osnr_flushed / (double)s.episode_services_processed : 0.0;
+    s.last_episode_disrupted = s.episode_disrupted_services;
+}
+
+
+// ---- measure_disruptions (envs/qrmsa.pyx:937-952) ---------------------------------------------------------------------
+// After an accept: every running service that shares a link with the new one (the new one included: it is already in the
+// running lists) and is not yet in the disrupted list gets its GSNR re-evaluated against all other running services; below
+// its modulation's minimum_osnr (no margin) it joins the list. The list membership is the sign bit of the record's
+// release time. Per measured service one pass over the whole service table (lanes over records).
+template <bool R32>
+__device__ __forceinline__ int measure_disruptions(Ctx &c, uint64_t nm0, uint64_t nm1) {
+    const Params &P = c.P;
+    const int L = gn_build_list<R32>(c, nm0, nm1);          // services on the new service's links
+    int newly = 0;
+    for (int j = 0; j < L; j++) {
+        const int iy = c.list[j];
+        const float ry = c.sr[iy];
+        if (ry < 0.f) continue;                              // already in disrupted_services_list
+        const uint32_t ay = c.sa[iy], by = c.sb[iy];
+        const int py = uniform_i32(rec_path<R32>(ay, by)), sy = uniform_i32(rec_slot<R32>(ay, by));
+        const int ny = uniform_i32(rec_n<R32>(ay, by)), my = uniform_i32(rec_mod<R32>(ay, by));
+        uint64_t ym0, ym1;
+        if (R32) { ym0 = ay; ym1 = 0; } else { ym0 = G(P.path_mask)[2 * py]; ym1 = G(P.path_mask)[2 * py + 1]; }
+        const int c2 = 2 * sy + ny;
+        double part = 0.0;
+        for (int base = 0; base < c.active; base += kWave) {
+            const int iz = base + c.lane;
+            if (iz >= c.active || iz == iy) continue;        // itself excluded (service_id test of core/osnr.pyx:65)
+            const uint32_t a = c.sa[iz], b = c.sb[iz];
+            uint64_t m0, m1;
+            if (R32) { m0 = a & (uint32_t)ym0; m1 = 0; }
+            else { int pk = a & 0xFFFF; m0 = G(P.path_mask)[2 * pk] & ym0; m1 = G(P.path_mask)[2 * pk + 1] & ym1; }
+            if (!(m0 | m1)) continue;
+            const int sk = rec_slot<R32>(a, b), nk = rec_n<R32>(a, b), mk = rec_mod<R32>(a, b);
+            const int adi = abs((2 * sk + nk) - c2);
+            double A, corr;
+            if (nk <= P.tab_nmax) {
+                const auto *t = G(reinterpret_cast<const double *>(P.pair_tab)) + 2 * ((nk - 1) * P.tab_stride + adi);
+                A = t[0]; corr = c.phi[mk] * t[1];
+            } else {
+                double bk = P.slot_bw * nk, adf = (0.5 * P.slot_bw) * (double)adi, ck = P.alpha0_cl * bk;
+                A = asinh_diff(ck * (adf + 0.5 * bk), ck * (adf - 0.5 * bk));
+                corr = c.phi[mk] * (bk / adf);
+            }
+            double w1 = 0.0, w2 = 0.0;
+            while (m0) { int l = __ffsll((unsigned long long)m0) - 1; m0 &= m0 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
+            while (m1) { int l = 64 + __ffsll((unsigned long long)m1) - 1; m1 &= m1 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
+            part += A * w1 - corr * w2;
+        }
+        if (c.lane == 0) part += G(P.path_w1)[py] * G(P.self_asinh)[ny];
+        const double total = wave_sum(part);
+        const double bw = P.slot_bw * ny;
+        const double fc = P.f0 + (P.slot_bw * sy) + (P.slot_bw * (ny / 2.0));
+        const double acc = (bw * fc * G(P.path_ase)[py]) * c.rp[0] + (G(P.nli_coef)[ny] * c.rp[1]) * total;
+        const double lim = c.lim0[my];
+        int below;                                            // osnr_svc < minimum_osnr ?
+        if (acc >= lim * (1.0 + 1e-9)) below = 1;
+        else if (acc <= lim * (1.0 - 1e-9)) below = 0;
+        else below = 10.0 * log10(1.0 / acc) < P.mod_thr[my];
+        if (uniform_i32(below)) {
+            if (c.lane == 0) c.sr[iy] = -ry;
+            newly++;
+        }
+    }
+    __syncthreads();
+    return newly;
 }
 
 // ---- one request: apply the choice (envs/qrmsa.pyx:838-1065) ----------------------------------------------------
@@ -888,6 +959,11 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
         c.active++;
     }
     __syncthreads();
+    if (outcome == 0 && P.measure_disruptions) {
+        const int newly = measure_disruptions<R32>(c, ch.m0, R32 ? 0 : G(P.path_mask)[2 * ch.path + 1]);
+        if (newly && c.lane == 0) { e->st.disrupted_services += newly; e->st.episode_disrupted_services += newly; }
+        __syncthreads();
+    }
     draw_next(c);                                 // first half of _next_service (:1079-1111)
     STAMP(c, 6);
     release_due<R32>(c, e->cur_at);               // second half of _next_service (:1113-1122)
@@ -1265,6 +1341,7 @@ __device__ __forceinline__ void load_state(Ctx &c) {
     if (c.e->have_request) prefetch_first_path(c, c.e->cur_src, c.e->cur_dst);
     // per-replica acceptance limits in the linear domain (see qot_ok)
     if (c.lane < P.n_mods) c.lim[c.lane] = pow(10.0, -(P.mod_thr[c.lane] + c.e->margin) / 10.0);
+    if (P.measure_disruptions && c.lane < P.n_mods) c.lim0[c.lane] = pow(10.0, -P.mod_thr[c.lane] / 10.0);
     if (c.lane < kMaxMods) c.phi[c.lane] = c.lane < P.n_mods ? P.mod_phi53[c.lane] : 0.0;
     if (c.lane == 0) { c.rp[0] = 1.0 / c.e->launch_power; c.rp[1] = c.e->launch_power * c.e->launch_power; }
     // slots needed by the current request (kept in LDS between requests, recomputed on load)

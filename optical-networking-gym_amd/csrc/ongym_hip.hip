@@ -36,7 +36,7 @@ __global__ __launch_bounds__(64, WAVES) void k_run(const Params *__restrict__ Pp
     c.stamp_last = __builtin_amdgcn_s_memtime();
 #endif
     if (POLICY == ONGYM_POLICY_HIGHEST_SNR) {   // extra LDS: Fx f64[2S+2] | Vw u64[8*16] | xlist u16[2S+2] | needx u8[2S+2]
-        c.fl.Fx = reinterpret_cast<double *>(smem + lds_bytes(P.n_links, P.row_words, P.capacity, P.uniform_alpha));
+        c.fl.Fx = reinterpret_cast<double *>(smem + lds_bytes(P.n_links, P.row_words, P.capacity, P.uniform_alpha, P.measure_disruptions));
         c.fl.Vw = reinterpret_cast<uint64_t *>(c.fl.Fx + 2 * P.n_slots + 2);
         c.fl.xlist = reinterpret_cast<uint16_t *>(c.fl.Vw + kMaxMods * kMaxRowWords);
         c.fl.needx = reinterpret_cast<uint8_t *>(c.fl.xlist + 2 * P.n_slots + 2);
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64) void k_observe(const Params *__restrict__ Pp, f
     c.paths_tried = 0; c.path_hops = 0; c.active_sum = 0;
     ctx_bind(c, smem);
     load_state(c);
-    double *Fx = reinterpret_cast<double *>(smem + lds_bytes(P.n_links, P.row_words, P.capacity, P.uniform_alpha));
+    double *Fx = reinterpret_cast<double *>(smem + lds_bytes(P.n_links, P.row_words, P.capacity, P.uniform_alpha, P.measure_disruptions));
     const size_t obs_dim = 3 + P.k_paths + (size_t)P.k_paths * P.n_mods * 12;
     const size_t nact = (size_t)P.k_paths * P.n_mods * P.n_slots + 1;
     // extra LDS of the observation kernel: Fx f64[2S+2] | Vw u64[8*16] | xlist u16[2S+2] | needx u8[2S+2]
@@ -181,7 +181,8 @@ __global__ __launch_bounds__(64) void k_query(const Params *__restrict__ Pp, int
             uint32_t a = c.sa[i], b = c.sb[i];
             o[i].path_id = rec_path<R32>(a, b); o[i].slot = (int16_t)rec_slot<R32>(a, b);
             o[i].nslots = (int16_t)rec_n<R32>(a, b); o[i].modulation = (int16_t)rec_mod<R32>(a, b);
-            o[i].reserved = 0; o[i].release_time = c.sr[i];
+            o[i].reserved = c.sr[i] < 0.f ? 1 : 0;   // 1: in the disrupted list (measure_disruptions)
+            o[i].release_time = fabsf(c.sr[i]);
         }
     } else if (what == kQCandidates) {  // _get_candidates on a caller-supplied row: path = total_slots, n = nslots
         const int total = path;
@@ -316,6 +317,7 @@ static int build(ongym_env *env, const ongym_config *c) {
     P.batch = c->batch; P.capacity = c->capacity; P.episode_length = c->episode_length; P.auto_reset = c->auto_reset;
     P.bit_rate_mode = c->bit_rate_mode; P.n_bit_rates = c->n_bit_rates; P.br_lo = c->bit_rate_lo; P.br_hi = c->bit_rate_hi;
     P.req_mode = kReqNone;
+    P.measure_disruptions = c->measure_disruptions ? 1 : 0;
     P.f0 = c->frequency_start; P.slot_bw = c->slot_bandwidth; P.channel_width = c->channel_width;
     P.mean_holding = c->mean_holding_time;
     P.max_bit_rate = c->max_bit_rate;
@@ -337,6 +339,7 @@ static int build(ongym_env *env, const ongym_config *c) {
         if (a != c->link_alpha[0]) uniform = false;
     }
     P.uniform_alpha = uniform ? 1 : 0;
+    if (c->measure_disruptions && !uniform) return fail_arg(env, "measure_disruptions needs uniform attenuation", ONGYM_E_LIMIT);
     P.rec32 = (E <= 32 && NP <= 512 && c->n_slots <= 1023) ? 1 : 0;
     P.alpha0_cl = cl[0];
     std::vector<uint64_t> mask((size_t)NP * 2, 0);
@@ -484,7 +487,7 @@ static int build(ongym_env *env, const ongym_config *c) {
         for (size_t i = 0; i < all.size(); i++) all[i] = row[i % P.row_words];
         HIP_TRY(env, hipMemcpy(P.occ, all.data(), all.size() * 8, hipMemcpyHostToDevice));
     }
-    env->lds = lds_bytes(E, P.row_words, c->capacity, P.uniform_alpha);
+    env->lds = lds_bytes(E, P.row_words, c->capacity, P.uniform_alpha, P.measure_disruptions);
     if (env->lds > 64 * 1024) {
         if (env->lds > 160 * 1024) return fail_arg(env, "state does not fit the 160 KiB LDS: lower capacity", ONGYM_E_LIMIT);
 #define ONGYM_SET_LDS(K) HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->lds))

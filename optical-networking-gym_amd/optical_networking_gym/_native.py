@@ -32,7 +32,7 @@ class OngymConfig(C.Structure):
         ("max_hops", C.c_int32), ("n_mods", C.c_int32), ("n_slots", C.c_int32),
         ("batch", C.c_int32), ("capacity", C.c_int32), ("episode_length", C.c_int32), ("auto_reset", C.c_int32),
         ("bit_rate_mode", C.c_int32), ("n_bit_rates", C.c_int32), ("bit_rate_lo", C.c_int32),
-        ("bit_rate_hi", C.c_int32), ("device", C.c_int32), ("io_device", C.c_int32), ("reserved0", C.c_int32),
+        ("bit_rate_hi", C.c_int32), ("device", C.c_int32), ("io_device", C.c_int32), ("measure_disruptions", C.c_int32),
         ("frequency_start", C.c_double), ("slot_bandwidth", C.c_double), ("channel_width", C.c_double),
         ("launch_power_w", C.c_double), ("margin", C.c_double), ("load", C.c_double),
         ("mean_holding_time", C.c_double),
@@ -59,11 +59,11 @@ STATS_DTYPE = np.dtype([
     ("bit_rate_requested", "<f8"), ("bit_rate_provisioned", "<f8"),
     ("episode_bit_rate_requested", "<f8"), ("episode_bit_rate_provisioned", "<f8"),
     ("rejected", "<i8"), ("episode_modulation_hist", "<i8", (8,)), ("episode_osnr_sum", "<f8"),
-    ("episodes_completed", "<i8"),
+    ("episodes_completed", "<i8"), ("disrupted_services", "<i8"), ("episode_disrupted_services", "<i8"),
     ("last_episode_processed", "<i8"), ("last_episode_accepted", "<i8"), ("last_rejected", "<i8"),
     ("last_service_blocking_rate", "<f8"), ("last_episode_service_blocking_rate", "<f8"),
     ("last_bit_rate_blocking_rate", "<f8"), ("last_episode_bit_rate_blocking_rate", "<f8"),
-    ("last_modulation_hist", "<i8", (8,)), ("last_mean_gsnr", "<f8"),
+    ("last_modulation_hist", "<i8", (8,)), ("last_mean_gsnr", "<f8"), ("last_episode_disrupted", "<i8"),
     ("total_steps", "<i8"), ("total_accepted", "<i8"), ("total_gn_evals", "<i8"),
     ("total_interferer_terms", "<i8"), ("total_paths_tried", "<i8"), ("total_path_hops", "<i8"),
     ("total_gn_shortcuts", "<i8"), ("total_active_sum", "<i8"), ("current_time", "<f8"), ("active", "<i4"), ("flags", "<i4")], align=True)
@@ -81,7 +81,7 @@ class ConfigHolder:
                  bit_rate_lower_bound: float = 25.0, bit_rate_higher_bound: float = 100.0,
                  launch_power_dbm: float = 0.0, frequency_start: float = 3e8 / 1565e-9,
                  frequency_slot_bandwidth: float = 12.5e9, margin: float = 0.0, channel_width: float = 12.5,
-                 device: int = 0, io_device: bool = False,
+                 device: int = 0, io_device: bool = False, measure_disruptions: bool = False,
                  replica_launch_power_dbm: Optional[Sequence[float]] = None,
                  replica_load: Optional[Sequence[float]] = None,
                  replica_margin: Optional[Sequence[float]] = None):
@@ -121,6 +121,7 @@ class ConfigHolder:
         c.n_bit_rates = len(rates)
         c.bit_rate_lo, c.bit_rate_hi = int(bit_rate_lower_bound), int(bit_rate_higher_bound)  # qrmsa.pyx:250-254
         c.device, c.io_device = int(device), int(bool(io_device))
+        c.measure_disruptions = int(bool(measure_disruptions))
         c.frequency_start, c.slot_bandwidth = float(frequency_start), float(frequency_slot_bandwidth)
         c.channel_width = float(channel_width)
         c.launch_power_w = 10 ** ((float(launch_power_dbm) - 30) / 10)  # qrmsa.pyx:288

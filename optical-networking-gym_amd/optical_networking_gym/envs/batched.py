@@ -38,7 +38,7 @@ class BatchedQRMSAEnv:
         mtc = kwargs.pop("modulations_to_consider", 6)
         modulations = list(modulations)[:min(mtc, len(modulations))] if mtc < len(modulations) else list(modulations)
         for dead in ("seed", "allow_rejection", "reset", "file_name", "blocks_to_consider", "gen_observation",
-                     "measure_disruptions", "defragmentation", "n_defrag_services", "bands", "bandwidth", "k_paths"):
+                     "defragmentation", "n_defrag_services", "bands", "bandwidth", "k_paths"):
             kwargs.pop(dead, None)
         self.holder = nat.ConfigHolder(tables, modulations=modulations, batch=batch_size, capacity=capacity,
                                        auto_reset=auto_reset, device=device, io_device=io_device, **kwargs)

@@ -11,7 +11,9 @@ this view does no slot-grid or GN arithmetic of its own, it only converts betwee
 heuristics; batch-scale use goes through `envs.batched.BatchedQRMSAEnv`.
 
 `gen_observation=True` returns the device-computed observation vector and action mask (`ongym_observe`).
-Not covered yet (raise NotImplementedError rather than silently differ): `measure_disruptions`, `defragmentation`, `bands` (quirk Q9), per-service CSV (`file_name`).
+`measure_disruptions=True` counts disrupted services on device.
+Not covered yet (raise NotImplementedError rather than silently differ): `defragmentation`, `bands` (quirk Q9), per-service
+CSV (`file_name`).
 """
 from __future__ import annotations
 
@@ -94,8 +96,9 @@ class QRMSAEnv:
         if gen_observation and (bit_rate_selection != "discrete" or modulations_to_consider < len(topology.graph.get("modulations", []))):
             raise NotImplementedError("gen_observation=True needs discrete bit rates and modulations_to_consider == "
                                       "len(modulations) (the reference's observation() reads max(bit_rates), qrmsa.pyx:679)")
-        if measure_disruptions or defragmentation or bands or file_name:
-            raise NotImplementedError("measure_disruptions / defragmentation / bands / file_name are not built yet")
+        if defragmentation or bands or file_name:
+            raise NotImplementedError("defragmentation / bands / file_name are not built yet")
+        self.measure_disruptions = bool(measure_disruptions)
         if seed is not None and not isinstance(seed, (int, np.integer)):
             raise ValueError("Seed must be an integer.")
         self.topology = topology
@@ -137,7 +140,7 @@ class QRMSAEnv:
             node_request_probabilities=node_request_probabilities, bit_rate_lower_bound=bit_rate_lower_bound,
             bit_rate_higher_bound=bit_rate_higher_bound, launch_power_dbm=launch_power_dbm,
             frequency_start=frequency_start, frequency_slot_bandwidth=frequency_slot_bandwidth, margin=margin,
-            channel_width=channel_width)
+            channel_width=channel_width, measure_disruptions=measure_disruptions)
         if requests is not None:
             self._dev.set_requests(requests)           # trace replay (parity tests)
         else:
@@ -254,7 +257,10 @@ class QRMSAEnv:
             "episode_service_blocking_rate": (ep - ea) / ep if ep > 0 else 0.0,
             "bit_rate_blocking_rate": (brq - brp) / brq if brq > 0 else 0.0,
             "episode_bit_rate_blocking_rate": (ebrq - ebrp) / ebrq if ebrq > 0 else 0.0,
-            "disrupted_services": 0.0, "episode_disrupted_services": 0.0,
+            # :1035-1041 — the global ratio is a true division, the episode one divides two C ints (always 0 unless
+            # every accepted service was disrupted)
+            "disrupted_services": (float(st["disrupted_services"]) / sa) if (st["disrupted_services"] > 0 and sa > 0) else 0.0,
+            "episode_disrupted_services": float(int(st["episode_disrupted_services"]) // ea) if (st["episode_disrupted_services"] > 0 and ea > 0) else 0.0,
             "osnr": float(rec["osnr"]), "osnr_req": float(osnr_req),
             "chosen_path_index": int(rec["route"]), "chosen_slot": int(rec["slot"]),
             "episode_defrag_cicles": 0, "episode_service_realocations": 0,

@@ -35,6 +35,7 @@ typedef struct {
     double center_frequency, bandwidth, launch_power;
     double osnr, ase, nli;
     int accepted;
+    int disrupted;      /* member of disrupted_services_list (envs/qrmsa.pyx:949-952) */
 } orc_service;
 
 typedef struct {
@@ -66,6 +67,7 @@ typedef struct orc_env {
     int64_t bl_reject, ep_mod_hist[8];
     double ep_osnr_sum; int64_t ep_services_listed; /* for mean_gsnr: topology.graph["services"] */
     int64_t episodes_completed;
+    int64_t disrupted_services, ep_disrupted_services;   /* envs/qrmsa.pyx:315-316, 468-469 */
     ongym_stats last; /* snapshot at last terminal step */
     int64_t total_steps, total_accepted, total_gn, total_terms, total_paths, total_hops, total_active_sum;
     /* request source */
@@ -225,6 +227,7 @@ int orc_reset(orc_env *e) {
     memset(e->ep_mod_hist, 0, sizeof(e->ep_mod_hist));
     e->bit_rate_requested = 0.0; e->bit_rate_provisioned = 0.0;   /* :466-467 */
     e->ep_osnr_sum = 0.0; e->ep_services_listed = 0;              /* topology.graph["services"] = [] */
+    e->disrupted_services = 0; e->ep_disrupted_services = 0;      /* :432, 468-469 */
     e->n_running = 0; memset(e->run_cnt, 0, sizeof(int32_t) * E);
     e->n_pool_free = 0;
     for (int i = e->pool_cap - 1; i >= 0; i--) e->pool_free[e->n_pool_free++] = i;
@@ -341,6 +344,25 @@ static void gn_state(orc_env *e, int path_id, int slot, int n, double out[3], in
             count ? &e->total_terms : 0);
 }
 void orc_gn(orc_env *e, int path_id, int slot, int n, double out[3]) { gn_state(e, path_id, slot, n, out, 0); }
+
+/* GN of a RUNNING service against the current state, itself excluded by service_id (core/osnr.pyx:65) */
+static void gn_running(orc_env *e, int32_t si, double out[3]) {
+    const orc_service *y = &e->pool[si];
+    int H = e->cfg.max_hops, hops = e->path_hops[y->path_id];
+    const orc_intf *lists[ORC_MAX_HOPS]; int counts[ORC_MAX_HOPS];
+    orc_intf *buf = (orc_intf *)e->scratch_intf;
+    size_t off = 0;
+    for (int h = 0; h < hops; h++) {
+        int l = e->path_links[y->path_id * H + h];
+        lists[h] = &buf[off]; counts[h] = e->run_cnt[l];
+        for (int k = 0; k < e->run_cnt[l]; k++) {
+            const orc_service *s = &e->pool[e->run[(size_t)l * e->pool_cap + k]];
+            buf[off].fc = s->center_frequency; buf[off].bw = s->bandwidth; buf[off].se = e->mod_se[s->mod];
+            buf[off].id = s->id; off++;
+        }
+    }
+    gn_core(e, y->path_id, y->center_frequency, y->bandwidth, y->launch_power, y->id, lists, counts, out, 0);
+}
 
 /* GN with explicit per-link interferer lists (for the captured known-answer tests):
  * intf = flat (slot, n, se) triples, link h owns counts[h] consecutive triples. */
@@ -541,6 +563,7 @@ static void snapshot_terminal(orc_env *e) {
         ? (e->ep_bit_rate_requested - e->ep_bit_rate_provisioned) / e->ep_bit_rate_requested : 0.0;
     memcpy(s->last_modulation_hist, e->ep_mod_hist, sizeof(e->ep_mod_hist));
     s->last_mean_gsnr = e->ep_services_listed ? e->ep_osnr_sum / (double)e->ep_services_listed : 0.0;
+    s->last_episode_disrupted = e->ep_disrupted_services;
 }
 
 /* ---- step (envs/qrmsa.pyx:838-1065), gen_observation=False, measure_disruptions=False, no CSV ------------------ */
@@ -581,6 +604,30 @@ int orc_step(orc_env *e, int action, ongym_step_rec *out) {
             return ONGYM_E_STATE;
         }
     }
+    /* measure_disruptions (envs/qrmsa.pyx:937-952): services on the new service's links (itself included, it is already in
+     * the running lists) that are not yet in the disrupted list are re-evaluated against minimum_osnr (no margin) */
+    if (e->cfg.measure_disruptions && e->cur.accepted) {
+        int H = e->cfg.max_hops, p = e->cur.path_id;
+        int32_t *todo = (int32_t *)malloc(sizeof(int32_t) * (size_t)(e->n_running + 1));
+        int nt = 0;
+        for (int h = 0; h < e->path_hops[p]; h++) {
+            int l = e->path_links[p * H + h];
+            for (int k = 0; k < e->run_cnt[l]; k++) {
+                int32_t si = e->run[(size_t)l * e->pool_cap + k];
+                int seen = e->pool[si].disrupted;
+                for (int q = 0; q < nt && !seen; q++) seen = todo[q] == si;
+                if (!seen) todo[nt++] = si;
+            }
+        }
+        for (int q = 0; q < nt; q++) {
+            double o[3];
+            gn_running(e, todo[q], o);
+            if (o[0] < e->mod_thr[e->pool[todo[q]].mod]) {
+                e->pool[todo[q]].disrupted = 1; e->disrupted_services++; e->ep_disrupted_services++;
+            }
+        }
+        free(todo);
+    }
     r.accepted = (uint8_t)e->cur.accepted;
     if (!e->cur.accepted) { r.route = (action == reject) ? -1 : r.route; }
     r.reward = (action != reject) ? reward(e) : -6.0;              /* :992-995 */
@@ -610,6 +657,7 @@ void orc_stats(const orc_env *e, ongym_stats *s) {
     s->rejected = e->bl_reject;
     memcpy(s->episode_modulation_hist, e->ep_mod_hist, sizeof(e->ep_mod_hist));
     s->episode_osnr_sum = e->ep_osnr_sum; s->episodes_completed = e->episodes_completed;
+    s->disrupted_services = e->disrupted_services; s->episode_disrupted_services = e->ep_disrupted_services;
     s->total_steps = e->total_steps; s->total_accepted = e->total_accepted; s->total_gn_evals = e->total_gn;
     s->total_interferer_terms = e->total_terms; s->total_paths_tried = e->total_paths;
     s->total_path_hops = e->total_hops; s->total_active_sum = e->total_active_sum;

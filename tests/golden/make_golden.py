@@ -170,7 +170,7 @@ def link_state(env, link):
 
 def run_trajectory(tag, topo_name, seed, load, S, episodes, episode_length=1000, bit_rates=(10, 40, 100, 400),
                    launch_power_dbm=0.0, margin=0.0, bit_rate_selection="discrete", scripted=False,
-                   gn_every=41, snap_steps=(100, 400, 700, 998), k=5, policy="first_fit"):
+                   gn_every=41, snap_steps=(100, 400, 700, 998), k=5, policy="first_fit", measure_disruptions=False):
     topo = load_topology(topo_name, k)
     nodes = list(topo.nodes())
     gn_samples = []
@@ -194,7 +194,7 @@ def run_trajectory(tag, topo_name, seed, load, S, episodes, episode_length=1000,
             num_spectrum_resources=S, launch_power_dbm=launch_power_dbm, bandwidth=S * 12.5e9,
             frequency_start=3e8 / 1565e-9, frequency_slot_bandwidth=12.5e9, bit_rate_selection=bit_rate_selection,
             bit_rates=bit_rates, bit_rate_lower_bound=25, bit_rate_higher_bound=100, margin=margin, file_name="",
-            measure_disruptions=False, k_paths=k, modulations_to_consider=6, defragmentation=False,
+            measure_disruptions=measure_disruptions, k_paths=k, modulations_to_consider=6, defragmentation=False,
             n_defrag_services=0, gen_observation=False)
     finally:
         random.Random = _OrigRandom
@@ -242,7 +242,7 @@ def run_trajectory(tag, topo_name, seed, load, S, episodes, episode_length=1000,
                 steps.append(dict(action=int(action), accepted=0, route=-1, mod=-1, slot=-1, n=0, osnr=0.0, ase=0.0,
                                   nli=0.0, reward=float(reward), term=0, bres=int(bool(bres)), bosnr=int(bool(bosnr)),
                                   active=len(env.env.topology.graph["running_services"]), retry=1,
-                                  ep_acc=-1))
+                                  ep_acc=-1, disr=0.0, ep_disr=0.0))
                 gstep += 1
                 continue
             svc = env.env.topology.graph["services"][-1]
@@ -256,7 +256,8 @@ def run_trajectory(tag, topo_name, seed, load, S, episodes, episode_length=1000,
                               osnr=float(svc.OSNR), ase=float(svc.ASE), nli=float(svc.NLI), reward=float(reward),
                               term=int(done), bres=int(bool(bres)), bosnr=int(bool(bosnr)),
                               active=len(env.env.topology.graph["running_services"]), retry=0,
-                              ep_acc=int(info["episode_services_accepted"])))
+                              ep_acc=int(info["episode_services_accepted"]),
+                              disr=float(info["disrupted_services"]), ep_disr=float(info["episode_disrupted_services"])))
             reqs.append(request_tuple(env)); kinds.append(1)
             if ep == 0 and estep in snap_steps:
                 grid = np.asarray(env.env.topology.graph["available_slots"], dtype=np.uint8)
@@ -280,7 +281,8 @@ def run_trajectory(tag, topo_name, seed, load, S, episodes, episode_length=1000,
     for key, dt in (("action", np.int32), ("accepted", np.uint8), ("route", np.int8), ("mod", np.int8),
                     ("slot", np.int16), ("n", np.int16), ("osnr", np.float64), ("ase", np.float64),
                     ("nli", np.float64), ("reward", np.float64), ("term", np.uint8), ("bres", np.uint8),
-                    ("bosnr", np.uint8), ("active", np.int32), ("retry", np.uint8), ("ep_acc", np.int32)):
+                    ("bosnr", np.uint8), ("active", np.int32), ("retry", np.uint8), ("ep_acc", np.int32),
+                    ("disr", np.float64), ("ep_disr", np.float64)):
         out["st_" + key] = np.array([s[key] for s in steps], dtype=dt)
     if snaps:
         out["snap_step"] = np.array(snap_at, dtype=np.int32)
@@ -303,7 +305,7 @@ def run_trajectory(tag, topo_name, seed, load, S, episodes, episode_length=1000,
                 frequency_start=3e8 / 1565e-9, slot_bw=12.5e9, mean_holding=10800.0,
                 terminal_infos=terminal_infos, n_steps=len(steps), n_requests=len(reqs),
                 launch_power_w=float(env.env.launch_power), reject_action=int(reject), initial_resets=3,
-                policy=policy)
+                policy=policy, measure_disruptions=measure_disruptions)
     np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **out)
     json.dump(meta, open(os.path.join(HERE, f"{tag}.json"), "w"), indent=1)
     acc = out["st_accepted"].mean()
@@ -457,6 +459,9 @@ TRAJ = {
     # GN model for every valid start of every (path, modulation) pair
     "traj_nsfnet128_hsnr": dict(topo_name="nsfnet", seed=41, load=120, S=128, episodes=1, episode_length=700,
                                 policy="highest_snr", snap_steps=(100, 400, 650), gn_every=100003),
+    # measure_disruptions=True (qrmsa.pyx:937-952): NLI-dominated regime so that new services push old ones under threshold
+    "traj_nsfnet320_disr": dict(topo_name="nsfnet", seed=61, load=500, S=320, episodes=2, launch_power_dbm=3.0,
+                                measure_disruptions=True),
     "traj_nobeleu320_lb": dict(topo_name="nobel-eu", seed=18, load=700, S=320, episodes=1, policy="load_balancing",
                                launch_power_dbm=1.0),
 }

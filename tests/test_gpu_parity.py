@@ -348,3 +348,56 @@ def test_extreme_shapes_vs_oracle(tmp_path):
     assert_records_equal(got, want, "ring40/S1000")
     assert got["nslots"].max() >= 40 and (got["accepted"] == 0).any() and got["slot"].max() > 900
     np.testing.assert_array_equal(env.grid(3), oracles[3].grid())
+
+
+def test_measure_disruptions_vs_reference_and_oracle():
+    """measure_disruptions=True (qrmsa.pyx:937-952): per-episode disrupted counts against the reference's captured run,
+    then counts and the membership of the disrupted list against the oracle on device-generated traffic."""
+    meta, d = load_traj("traj_nsfnet320_disr")
+    env = make_env(meta, auto_reset=True, measure_disruptions=True)
+    env.set_requests(traj_requests(d))
+    for _ in range(meta["initial_resets"]):
+        env.reset()
+    o = OracleEnv(holder_for(meta, measure_disruptions=True))
+    o.set_trace(traj_requests(d))
+    for _ in range(meta["initial_resets"]):
+        o.reset()
+    done = 0
+    for chunk in (400, 598, 1, 600, 399):                       # 999 steps = one episode
+        rec = env.step_policy(chunk)[:, 0]
+        assert np.array_equal(rec["action"], d["st_action"][done:done + chunk])
+        for _ in range(chunk):
+            a, _, _ = o.policy_first_fit()
+            rc, r = o.step(a)
+            if r["terminated"]:
+                o.reset()
+        done += chunk
+        s, so = env.stats()[0], o.stats()
+        for f in ("disrupted_services", "episode_disrupted_services", "last_episode_disrupted", "services_accepted"):
+            assert s[f] == so[f], (done, f, s[f], so[f])
+        # the reference's info["disrupted_services"] at the last step of the chunk
+        assert abs(s["disrupted_services"] - d["st_disr"][done - 1] * s["services_accepted"]) < 1e-6 or rec["terminated"][-1]
+    assert env.stats()[0]["last_episode_disrupted"] > 5
+    # random traffic, per-replica power so that some replicas see many disruptions and some none
+    B, steps = 24, 700
+    lps = np.linspace(-2.0, 5.0, B)
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=320, batch=B, capacity=1024, load=500,
+              bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), auto_reset=True,
+              replica_launch_power_dbm=lps, measure_disruptions=True)
+    holder = nat.ConfigHolder(golden_tables("nsfnet"), **kw)
+    env = BatchedQRMSAEnv(tables=golden_tables("nsfnet"), modulations=jocn_modulations(), batch_size=B,
+                          num_spectrum_resources=320, capacity=1024, load=500, bit_rate_selection="discrete",
+                          bit_rates=(10, 40, 100, 400), replica_launch_power_dbm=lps, measure_disruptions=True)
+    env.seed(12); env.reset()
+    got = env.step_policy(steps)
+    st = env.stats()
+    for r in range(B):
+        oo = OracleEnv(holder, replica=r)
+        oo.seed(12); oo.reset()
+        want = oo.run_first_fit(steps)
+        assert np.array_equal(got["action"][:, r], want["action"])
+        so = oo.stats()
+        assert st[r]["disrupted_services"] == so["disrupted_services"], (r, st[r]["disrupted_services"], so["disrupted_services"])
+        flagged = env.services(r)
+        assert int(flagged["reserved"].sum()) <= so["disrupted_services"]      # some disrupted services have departed
+    assert st["disrupted_services"].max() > 10 and len(np.unique(st["disrupted_services"])) > 5

@@ -195,3 +195,31 @@ def test_other_policy_trajectory(tag):
             np.testing.assert_allclose(r["osnr"], d["st_osnr"][i], rtol=GSNR_RTOL)
         if r["terminated"]:
             env.reset()
+
+
+# ---- measure_disruptions (qrmsa.pyx:937-952) ---------------------------------------------------------------------------
+def test_measure_disruptions_trajectory():
+    meta, d = load_traj("traj_nsfnet320_disr")
+    assert meta["measure_disruptions"]
+    env = OracleEnv(holder_for(meta, measure_disruptions=True))
+    env.set_trace(traj_requests(d))
+    for _ in range(meta["initial_resets"]):
+        env.reset()
+    seen = 0
+    for i in range(meta["n_steps"]):
+        act, bres, bosnr = env.policy_first_fit()
+        assert act == d["st_action"][i], i
+        rc, r = env.step(act)
+        assert rc == 0 and r["accepted"] == d["st_accepted"][i]
+        s = env.stats()
+        # info["disrupted_services"] = float(disrupted_services) / services_accepted (qrmsa.pyx:1035-1036; the counter is
+        # zeroed by reset(), the divisor never is). The episode-level ratio of :1038-1041 divides two C ints under
+        # cdivision and is therefore always 0 in the reference's output.
+        want = d["st_disr"][i] * s["services_accepted"]
+        assert abs(s["disrupted_services"] - want) < 1e-6, (i, s["disrupted_services"], want)
+        assert d["st_ep_disr"][i] == (s["episode_disrupted_services"] // max(d["st_ep_acc"][i], 1) if d["st_ep_acc"][i] > 0 else 0)
+        seen = max(seen, int(s["disrupted_services"]))
+        if r["terminated"]:
+            assert s["last_episode_disrupted"] == s["episode_disrupted_services"]
+            env.reset()
+    assert seen > 5
