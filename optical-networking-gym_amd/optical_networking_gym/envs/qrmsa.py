@@ -12,8 +12,8 @@ heuristics; batch-scale use goes through `envs.batched.BatchedQRMSAEnv`.
 
 `gen_observation=True` returns the device-computed observation vector and action mask (`ongym_observe`).
 `measure_disruptions=True` counts disrupted services on device.
-Not covered yet (raise NotImplementedError rather than silently differ): `defragmentation`, `bands` (quirk Q9), per-service
-CSV (`file_name`).
+`bands` reproduces quirk Q9 (one slot per service); `file_name` writes the per-service CSV from the step records.
+Not covered yet (raise NotImplementedError rather than silently differ): `defragmentation`.
 """
 from __future__ import annotations
 
@@ -96,8 +96,10 @@ class QRMSAEnv:
         if gen_observation and (bit_rate_selection != "discrete" or modulations_to_consider < len(topology.graph.get("modulations", []))):
             raise NotImplementedError("gen_observation=True needs discrete bit rates and modulations_to_consider == "
                                       "len(modulations) (the reference's observation() reads max(bit_rates), qrmsa.pyx:679)")
-        if defragmentation or bands or file_name:
-            raise NotImplementedError("defragmentation / bands / file_name are not built yet")
+        if defragmentation:
+            raise NotImplementedError("defragmentation is not built yet")
+        if bands and gen_observation:
+            raise NotImplementedError("bands together with gen_observation=True is not built yet")
         self.measure_disruptions = bool(measure_disruptions)
         if seed is not None and not isinstance(seed, (int, np.integer)):
             raise ValueError("Seed must be an integer.")
@@ -118,7 +120,12 @@ class QRMSAEnv:
         self.max_modulation_idx = len(self.modulations) - 1
         self.modulations_to_consider = min(modulations_to_consider, len(self.modulations))
         self.allow_rejection = allow_rejection
-        self.bands, self.current_band = [], None
+        # multiband quirk Q9 (qrmsa.pyx:417-425, 1198-1205): with bands the slot count is computed with the C band's
+        # channel width in Hz, i.e. every service needs one slot
+        self.bands = list(bands) if bands else []
+        self.current_band = self.bands[1] if self.bands else None
+        self._slot_width = ((self.current_band.freq_end - self.current_band.freq_start) * 1e12 / self.current_band.num_slots
+                            if self.current_band is not None else self.channel_width)
         self.blocks_to_consider = blocks_to_consider
         self.input_seed = int(seed) % (2 ** 31) if seed is not None else int(np.random.SeedSequence().generate_state(1)[0] % (2 ** 31))
         self.action_space = _Discrete(self.k_paths * self.modulations_to_consider * self.num_spectrum_resources + 1)
@@ -140,13 +147,26 @@ class QRMSAEnv:
             node_request_probabilities=node_request_probabilities, bit_rate_lower_bound=bit_rate_lower_bound,
             bit_rate_higher_bound=bit_rate_higher_bound, launch_power_dbm=launch_power_dbm,
             frequency_start=frequency_start, frequency_slot_bandwidth=frequency_slot_bandwidth, margin=margin,
-            channel_width=channel_width, measure_disruptions=measure_disruptions)
+            channel_width=self._slot_width, measure_disruptions=measure_disruptions)
         if requests is not None:
             self._dev.set_requests(requests)           # trace replay (parity tests)
         else:
             # the reference's traffic RNG is unseeded (quirk Q2); here `seed` selects the device stream
             self._dev.seed(self.input_seed)
         self._sync_views = bool(sync_views)
+        self.file_stats = None
+        if file_name != "":   # per-service CSV of qrmsa.pyx:387-406, same name pattern and header
+            final_name = "_".join([file_name, str(topology.graph["name"]), str(self.launch_power_dbm), str(self.load),
+                                   str(seed) + ".csv"])
+            directory = os.path.dirname(final_name)
+            if directory and not os.path.exists(directory):
+                os.makedirs(directory, exist_ok=True)
+            self.final_file_name = final_name
+            self.file_stats = open(final_name, "wt", encoding="UTF-8")
+            self.file_stats.write("# Service stats file from simulator\n")
+            self.file_stats.write("id,source,destination,bit_rate,path_k,path_length,modulation,min_osnr,osnr,ase,nli,"
+                                  "disrupted_services,active_services\n")
+        self._disrupted_seen = 0
         self.current_service: Optional[Service] = None
         self.current_time = 0.0
         self._last_stats = None
@@ -210,6 +230,7 @@ class QRMSAEnv:
 
     def step(self, action: int):
         cur = self.current_service
+        running_before = len(self._dev.services(0)) if self.file_stats is not None else 0
         rec = self._dev.step(np.array([int(action)], np.int32))[0]
         obs, mask = (None, None) if (rec["flags"] & (nat.F_QOT_ERROR | nat.F_NO_REQUEST)) else self._blank_observation()
         if rec["flags"] & nat.F_QOT_ERROR:
@@ -245,6 +266,18 @@ class QRMSAEnv:
         self._refresh_views()
         st = self._last_stats
         terminated = bool(rec["terminated"])
+        if self.file_stats is not None:   # qrmsa.pyx:967-990
+            newly = int(st["disrupted_services"]) - self._disrupted_seen if int(st["disrupted_services"]) >= self._disrupted_seen else int(st["disrupted_services"])
+            self._disrupted_seen = int(st["disrupted_services"])
+            line = "{},{},{},{},".format(cur.service_id, cur.source_id, cur.destination_id, cur.bit_rate)
+            if cur.accepted:
+                line += "{},{},{},{},{},{},{},{},{}".format(
+                    cur.path.k, cur.path.length, cur.current_modulation.spectral_efficiency,
+                    cur.current_modulation.minimum_osnr, cur.OSNR, cur.ASE, cur.NLI, newly, running_before + 1)
+            else:
+                line += "-1,-1,-1,-1,-1,-1,-1,-1,-1"
+            self.file_stats.write(line + "\n")
+            self.file_stats.flush()
         # info of qrmsa.pyx:996-1050 is computed BEFORE the next request is drawn: undo that draw's increments
         sp, sa = int(st["services_processed"]) - 1, int(st["services_accepted"])
         ep, ea = int(st["episode_services_processed"]) - 1, int(st["episode_services_accepted"])
@@ -283,7 +316,7 @@ class QRMSAEnv:
     def get_number_slots(self, service, modulation) -> int:
         # integer ceil of bit_rate / (SE * 12.5): answered by the same table the kernels use is not exposed per call;
         # this is pure request arithmetic (no state), identical to qrmsa.pyx:1198-1205 with bands unset
-        return int(math.ceil(float(np.float32(service.bit_rate)) / (modulation.spectral_efficiency * self.channel_width)))
+        return int(math.ceil(float(np.float32(service.bit_rate)) / (modulation.spectral_efficiency * self._slot_width)))
 
     def get_available_slots(self, path) -> np.ndarray:
         return self._dev.available_slots(0, int(path.id))
@@ -337,4 +370,7 @@ class QRMSAEnv:
         return int(a[0]), bool(f[0] & nat.F_BLOCKED_RESOURCES), bool(f[0] & nat.F_BLOCKED_OSNR)
 
     def close(self):
+        if self.file_stats is not None:
+            self.file_stats.close()
+            self.file_stats = None
         self._dev.close()

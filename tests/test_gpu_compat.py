@@ -170,3 +170,31 @@ def test_gen_observation_through_the_wrapper():
         np.testing.assert_array_equal(env.action_masks(), want_mask)
         assert info["mask"][int(d["action"][i])] == 1          # the first-fit action is always inside the mask
         obs, reward, done, truncated, info = env.step(int(d["action"][i]))
+
+
+def test_bands_quirk_and_service_csv(tmp_path):
+    """bands=[S, C, L] (graph_launch_power.py:108): every service needs ONE slot (quirk Q9: SURVEY measured
+    400 G -> [1,1,1,1,1,1] in the reference); file_name: per-service CSV with the reference's header (qrmsa.pyx:387-406)."""
+    from optical_networking_gym.core.bands import BandC, BandL, BandS
+    topology = get_topology(bundled_topology_path("nsfnet_chen.txt"), None, jocn_modulations(), 80, 0.2, 4.5, 5)
+    prefix = str(tmp_path / "svc")
+    env = QRMSAEnvWrapper(topology=topology, seed=7, load=300, episode_length=40, num_spectrum_resources=320,
+                          bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), gen_observation=False,
+                          bands=[BandS(), BandC(), BandL()], file_name=prefix, measure_disruptions=True)
+    sim = get_qrmsa_env(env)
+    assert sim.current_band.name == "C"
+    env.reset()
+    done = False
+    while not done:
+        cur = sim.current_service
+        assert [sim.get_number_slots(cur, m) for m in sim.modulations] == [1, 1, 1, 1, 1, 1]
+        action, _, _ = heuristic_shortest_available_path_first_fit_best_modulation(env)
+        _, _, done, _, info = env.step(action)
+    assert all(s.number_slots == 1 for s in sim.topology.graph["services"] if s.accepted)
+    env.close()
+    lines = open(sim.final_file_name).read().splitlines()
+    assert lines[0] == "# Service stats file from simulator"
+    assert lines[1] == ("id,source,destination,bit_rate,path_k,path_length,modulation,min_osnr,osnr,ase,nli,"
+                        "disrupted_services,active_services")
+    assert len(lines) == 2 + 39 and len(lines[2].split(",")) == 13
+    assert sim.final_file_name.endswith("_nsfnet_chen_0.0_300.0_7.csv")
