@@ -364,10 +364,14 @@ class QRMSAEnv:
         route = self.k_shortest_paths[self.current_service.source, self.current_service.destination][path]
         return [grid[self.topology[l.node1][l.node2]["index"], :] for l in route.links]
 
-    def first_fit_action(self):
-        """The fused device policy (heuristics.py:923-966): (action, blocked_resources, blocked_osnr)."""
-        a, f = self._dev.policy_actions()
+    def policy_action(self, policy: int = nat.POLICY_FIRST_FIT):
+        """A fused device policy evaluated on the current request: (action, blocked_resources, blocked_osnr)."""
+        a, f = self._dev.policy_actions(policy)
         return int(a[0]), bool(f[0] & nat.F_BLOCKED_RESOURCES), bool(f[0] & nat.F_BLOCKED_OSNR)
+
+    def first_fit_action(self):
+        """heuristic_shortest_available_path_first_fit_best_modulation (heuristics.py:923-966) on device."""
+        return self.policy_action(nat.POLICY_FIRST_FIT)
 
     def close(self):
         if self.file_stats is not None:

@@ -3,13 +3,19 @@
 Reference: optical_networking_gym/heuristics/heuristics.py — `get_qrmsa_env` (:15-33), `get_action_index` (:36-54),
 `heuristic_shortest_available_path_first_fit_best_modulation` (:923-966), `heuristic_highest_snr` (:272-328).
 
-* The benchmark default (first fit) is answered by the policy fused on device (`ongym_policy_actions`).
+* First fit, highest SNR and load-balancing-best-modulation are answered by the policies fused on device
+  (`ongym_policy_actions`).
 * `heuristic_shortest_available_path_first_fit_best_modulation_plugin` is the same policy written against the plugin API
   only (k_shortest_paths / get_number_slots / get_available_slots / _get_candidates / calculate_osnr): it exists to show
   — and test — that plugins written for the reference run unchanged on the compatibility view.
 """
 from __future__ import annotations
 
+from typing import Optional
+
+import numpy as np
+
+from .. import _native as _nat
 from ..core.osnr import calculate_osnr
 from ..envs.qrmsa import QRMSAEnv
 
@@ -66,7 +72,51 @@ def heuristic_shortest_available_path_first_fit_best_modulation_plugin(env):
 
 
 def heuristic_highest_snr(env):
-    """Among every (path, modulation) pair's first-fit candidate that clears its threshold, take the highest GSNR."""
+    """Every valid start of every (path, modulation) pair; highest GSNR above threshold wins (reference :272-328).
+    Evaluated by the fused device policy (`ONGYM_POLICY_HIGHEST_SNR`)."""
+    return get_qrmsa_env(env).policy_action(_nat.POLICY_HIGHEST_SNR)
+
+
+def load_balancing_best_modulation(env):
+    """Least-loaded of the k paths, best modulation, first fit (reference :547-627). Fused device policy."""
+    return get_qrmsa_env(env).policy_action(_nat.POLICY_LOAD_BALANCING)
+
+
+def shortest_available_path_first_fit_best_modulation(mask: np.ndarray) -> Optional[int]:
+    """Mask-based first fit (reference :419-422): the first allowed action index."""
+    return int(np.flatnonzero(np.asarray(mask) == 1)[0])
+
+
+def rnd(mask: np.ndarray) -> Optional[int]:
+    """Uniformly random allowed action (reference :424-428)."""
+    return int(np.random.choice(np.flatnonzero(np.asarray(mask) == 1)))
+
+
+def _not_built(name, where):
+    def stub(*args, **kwargs):
+        raise NotImplementedError(f"{name} (reference heuristics.py:{where}) is not built yet; write it against the plugin "
+                                  f"API (get_available_slots / _get_candidates / calculate_osnr) or use a fused policy")
+    stub.__name__ = name
+    return stub
+
+
+# names the reference's example scripts import (graph_load.py:80-90, graph_launch_power.py:64-78); importing them works,
+# calling one that is not built fails loudly
+heuristic_from_mask = _not_built("heuristic_from_mask", "76-198")
+heuristic_load_balancing_first_fit = _not_built("heuristic_load_balancing_first_fit", "202-269")
+heuristic_lowest_fragmentation = _not_built("heuristic_lowest_fragmentation", "330-414")
+shortest_available_path_lowest_spectrum_best_modulation = _not_built(
+    "shortest_available_path_lowest_spectrum_best_modulation", "431-490")
+best_modulation_load_balancing = _not_built("best_modulation_load_balancing", "491-545")
+heuristic_mscl = _not_built("heuristic_mscl", "647-749")
+heuristic_mscl_simplified = _not_built("heuristic_mscl_simplified", "765-839")
+heuristic_mscl_sequential_simplified = _not_built("heuristic_mscl_sequential_simplified", "841-921")
+heuristic_psr = _not_built("heuristic_psr", "1019-1119")
+heuristic_exact_fit = _not_built("heuristic_exact_fit", "1121-1227")
+
+
+def heuristic_highest_snr_plugin(env):
+    """The same policy written against the plugin API only (slow: one device query per candidate)."""
     sim_env = get_qrmsa_env(env)
     service = sim_env.current_service
     best, best_osnr = None, float("-inf")

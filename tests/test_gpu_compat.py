@@ -6,7 +6,7 @@ import pytest
 from common import jocn_modulations, load_traj, traj_requests
 from optical_networking_gym.core.osnr import calculate_osnr
 from optical_networking_gym.heuristics.heuristics import (
-    get_action_index, get_qrmsa_env, heuristic_highest_snr,
+    get_action_index, get_qrmsa_env, heuristic_highest_snr, heuristic_highest_snr_plugin, load_balancing_best_modulation,
     heuristic_shortest_available_path_first_fit_best_modulation,
     heuristic_shortest_available_path_first_fit_best_modulation_plugin)
 from optical_networking_gym.topology import bundled_topology_path, get_topology
@@ -102,7 +102,9 @@ def test_plugin_api_policy_equals_fused_policy_and_reference():
     assert sim.encoded_decimal_to_array(get_action_index(sim, 2, 3, 17)) == [2, 3, 17]
     blocks, lengths = sim.get_available_blocks(0, n, 3)
     assert all(avail[b:b + l].all() for b, l in zip(blocks, lengths))
-    # highest-SNR plugin returns a feasible action the env accepts
+    # highest SNR: fused device policy == the same policy written against the plugin API; the env accepts its action
+    assert heuristic_highest_snr(env) == heuristic_highest_snr_plugin(env)
+    assert load_balancing_best_modulation(env)[0] != -1
     action, _, _ = heuristic_highest_snr(env)
     _, reward, _, _, info = env.step(action)
     assert reward == 0.0 or action == sim.reject_action
