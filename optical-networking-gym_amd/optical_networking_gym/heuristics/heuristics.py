@@ -126,17 +126,20 @@ def heuristic_highest_snr_plugin(env):
         for modulation_idx in range(sim_env.max_modulation_idx, -1, -1):
             modulation = sim_env.modulations[modulation_idx]
             slots = sim_env.get_number_slots(service, modulation)
-            starts = sim_env._get_candidates(avail, slots, sim_env.num_spectrum_resources) if slots > 0 else []
+            if slots <= 0:
+                continue
+            starts = sim_env._get_candidates(avail, slots, sim_env.num_spectrum_resources)
             if not starts:
                 no_slots = True
                 continue
-            _stage_candidate(sim_env, service, path, modulation, starts[0], slots)
-            osnr, _, _ = calculate_osnr(sim_env, service)
-            if osnr >= modulation.minimum_osnr + sim_env.margin:
-                if osnr > best_osnr:
-                    best, best_osnr = get_action_index(sim_env, path_idx, modulation_idx, starts[0]), osnr
-            else:
-                low_osnr = True
+            for start in starts:
+                _stage_candidate(sim_env, service, path, modulation, start, slots)
+                osnr, _, _ = calculate_osnr(sim_env, service)
+                if osnr >= modulation.minimum_osnr + sim_env.margin:
+                    if osnr > best_osnr:
+                        best, best_osnr = get_action_index(sim_env, path_idx, modulation_idx, start), osnr
+                else:
+                    low_osnr = True
     if best is None:
-        return env.action_space.n - 1, no_slots, low_osnr
+        return env.action_space.n - 1, (no_slots and not low_osnr), low_osnr
     return best, False, False
