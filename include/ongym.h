@@ -205,6 +205,10 @@ int ongym_observe(ongym_env *env, float *obs, uint8_t *mask);
 int ongym_query_available(ongym_env *env, int32_t replica, int32_t path_id, int32_t *out);
 /* calculate_osnr(env, service) (core/osnr.pyx:21-142) for a candidate (path, slot, nslots): out = gsnr, ase, nli dB */
 int ongym_query_gsnr(ongym_env *env, int32_t replica, int32_t path_id, int32_t slot, int32_t nslots, double out[3]);
+/* The same for `count` candidates of one replica in ONE launch (one wavefront per candidate) — what a plugin heuristic
+ * that scores every feasible start needs (heuristics.py:272-328, 330-416, 647-749): cands int32 [count][3] =
+ * {path_id, slot, nslots}; out double [count][3] = {gsnr, ase, nli} dB.  Host buffers. */
+int ongym_query_gsnr_many(ongym_env *env, int32_t replica, int32_t count, const int32_t *cands, double *out);
 /* QRMSAEnv._get_candidates(available_slots, n, total_slots) (qrmsa.pyx:515-541) on an ARBITRARY row (1 = free):
  * starts_out[total_slots] receives the feasible start slots in ascending order, *count their number.
  * total_slots <= 1023. State-independent (no replica argument). */

@@ -139,6 +139,31 @@ __global__ void k_rewind(Params P) {   // new trace: cursor back to 0
     P.env[r].req_index = 0;
 }
 
+// calculate_osnr for MANY candidates of one replica: one wavefront per candidate (cand = {path_id, slot, nslots}).
+template <bool UA, bool R32>
+__global__ __launch_bounds__(64) void k_query_gsnr_many(const Params *__restrict__ Pp, int replica, int count,
+                                                        const int32_t *__restrict__ cand, double *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const Params &P = *Pp;
+    if ((int)blockIdx.x >= count) return;
+    Ctx c(P);
+    c.lane = threadIdx.x;
+    c.replica = replica;
+    c.lane_terms = 0;
+    c.gn_evals = 0;
+    c.gn_skips = 0;
+    c.paths_tried = 0; c.path_hops = 0; c.active_sum = 0;
+    ctx_bind(c, smem);
+    load_state(c);
+    const int path = cand[3 * blockIdx.x], slot = cand[3 * blockIdx.x + 1], n = cand[3 * blockIdx.x + 2];
+    PathRef p = load_path(c, path);
+    int L = gn_build_list<R32>(c, p.m0, p.m1);
+    GnLin lin = gn_eval<UA, R32>(c, p, L, slot, n);
+    double g[3];
+    gn_to_db(lin, g);
+    if (c.lane == 0) { out[3 * blockIdx.x] = g[0]; out[3 * blockIdx.x + 1] = g[1]; out[3 * blockIdx.x + 2] = g[2]; }
+}
+
 enum { kQAvailable = 0, kQGsnr = 1, kQGrid = 2, kQServices = 3, kQRequest = 4, kQCandidates = 5, kQPathFree = 6 };
 
 template <bool UA, bool R32>
@@ -497,6 +522,8 @@ static int build(ongym_env *env, const ongym_config *c) {
         ONGYM_SET_LDS((k_run<false, true, 4, 1>)); ONGYM_SET_LDS((k_run<false, false, 4, 1>));
         ONGYM_SET_LDS((k_query<true, true>)); ONGYM_SET_LDS((k_query<true, false>));
         ONGYM_SET_LDS((k_query<false, true>)); ONGYM_SET_LDS((k_query<false, false>));
+        ONGYM_SET_LDS((k_query_gsnr_many<true, true>)); ONGYM_SET_LDS((k_query_gsnr_many<true, false>));
+        ONGYM_SET_LDS((k_query_gsnr_many<false, true>)); ONGYM_SET_LDS((k_query_gsnr_many<false, false>));
         ONGYM_SET_LDS(k_reset);
 #undef ONGYM_SET_LDS
     }
@@ -818,6 +845,45 @@ int ongym_query_gsnr(ongym_env *env, int32_t replica, int32_t path_id, int32_t s
     if (rc) return rc;
     HIP_TRY(env, hipMemcpyAsync(out, env->d_scratch_d, 3 * sizeof(double), hipMemcpyDeviceToHost, env->stream));
     HIP_TRY(env, hipStreamSynchronize(env->stream));
+    return ONGYM_OK;
+}
+
+int ongym_query_gsnr_many(ongym_env *env, int32_t replica, int32_t count, const int32_t *cands, double *out) {
+    if (!env || (count > 0 && (!cands || !out))) return ONGYM_E_ARG;
+    if (count < 0) return fail_arg(env, "negative candidate count");
+    if (count == 0) return ONGYM_OK;
+    if (replica < 0 || replica >= env->P.batch) return fail_arg(env, "replica out of range");
+    for (int32_t i = 0; i < count; i++) {    // every operand is checked on the host before the launch
+        const int32_t path = cands[3 * i], slot = cands[3 * i + 1], n = cands[3 * i + 2];
+        if (path < 0 || path >= env->P.n_paths) return fail_arg(env, "path id out of range");
+        if (slot < 0 || n <= 0 || slot + n > env->P.n_slots) return fail_arg(env, "slot range out of the grid");
+    }
+    HIP_TRY(env, hipSetDevice(env->cfg.device));
+    int32_t *d_c = nullptr;
+    double *d_o = nullptr;
+    HIP_TRY(env, hipMalloc(reinterpret_cast<void **>(&d_c), (size_t)count * 3 * sizeof(int32_t)));
+    if (hipMalloc(reinterpret_cast<void **>(&d_o), (size_t)count * 3 * sizeof(double)) != hipSuccess) {
+        (void)hipFree(d_c);
+        return fail_arg(env, "hipMalloc failed", ONGYM_E_HIP);
+    }
+    hipError_t e = hipMemcpyAsync(d_c, cands, (size_t)count * 3 * sizeof(int32_t), hipMemcpyHostToDevice, env->stream);
+#define ONGYM_LAUNCH_QM(UA, R)                                                                                      \
+    hipLaunchKernelGGL((k_query_gsnr_many<UA, R>), dim3(count), dim3(64), env->lds, env->stream, env->d_P, replica, \
+                       count, d_c, d_o)
+    if (e == hipSuccess) {
+        if (env->P.uniform_alpha) { if (env->P.rec32) ONGYM_LAUNCH_QM(true, true); else ONGYM_LAUNCH_QM(true, false); }
+        else { if (env->P.rec32) ONGYM_LAUNCH_QM(false, true); else ONGYM_LAUNCH_QM(false, false); }
+        e = hipGetLastError();
+    }
+#undef ONGYM_LAUNCH_QM
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_o, (size_t)count * 3 * sizeof(double), hipMemcpyDeviceToHost, env->stream);
+    hipError_t e2 = hipStreamSynchronize(env->stream);
+    (void)hipFree(d_c);
+    (void)hipFree(d_o);
+    if (e != hipSuccess || e2 != hipSuccess) {
+        env->err = std::string("ongym_query_gsnr_many: ") + hipGetErrorString(e != hipSuccess ? e : e2);
+        return ONGYM_E_HIP;
+    }
     return ONGYM_OK;
 }
 

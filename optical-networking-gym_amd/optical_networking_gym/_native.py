@@ -177,6 +177,7 @@ def _declare(lib):
     lib.ongym_observe.argtypes = [vp, vp, vp]
     lib.ongym_query_available.argtypes = [vp, C.c_int32, C.c_int32, vp]
     lib.ongym_query_gsnr.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]
+    lib.ongym_query_gsnr_many.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
     lib.ongym_query_grid.argtypes = [vp, C.c_int32, vp]
     lib.ongym_query_candidates.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp]
     lib.ongym_query_path_free.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]
@@ -191,7 +192,7 @@ def _declare(lib):
     lib.ongym_abi_version.argtypes = []
     lib.ongym_sizeof.argtypes = [C.c_int32]
     for name in ("ongym_create", "ongym_seed", "ongym_set_requests", "ongym_reset", "ongym_step_policy",
-                 "ongym_step_actions", "ongym_policy_actions", "ongym_observe", "ongym_query_available", "ongym_query_gsnr",
+                 "ongym_step_actions", "ongym_policy_actions", "ongym_observe", "ongym_query_available", "ongym_query_gsnr", "ongym_query_gsnr_many",
                  "ongym_query_grid", "ongym_query_services", "ongym_query_request", "ongym_stats_get", "ongym_sync",
                  "ongym_abi_version", "ongym_sizeof", "ongym_query_candidates", "ongym_query_path_free", "ongym_observe"):
         getattr(lib, name).restype = C.c_int32
@@ -199,7 +200,7 @@ def _declare(lib):
 
 EXPORTED_SYMBOLS = (
     "ongym_create", "ongym_destroy", "ongym_seed", "ongym_set_requests", "ongym_reset", "ongym_step_policy",
-    "ongym_step_actions", "ongym_policy_actions", "ongym_observe", "ongym_query_available", "ongym_query_gsnr", "ongym_query_grid",
+    "ongym_step_actions", "ongym_policy_actions", "ongym_observe", "ongym_query_available", "ongym_query_gsnr", "ongym_query_gsnr_many", "ongym_query_grid",
     "ongym_query_services", "ongym_query_request", "ongym_query_candidates", "ongym_query_path_free",
     "ongym_stats_get", "ongym_sync", "ongym_last_kernel_ms",
     "ongym_last_error", "ongym_abi_version", "ongym_sizeof")

@@ -142,6 +142,14 @@ class BatchedQRMSAEnv:
                     "ongym_query_gsnr")
         return out
 
+    def gsnr_many(self, replica: int, cands) -> np.ndarray:
+        """`calculate_osnr` for many candidates `(path_id, slot, nslots)` of one replica in one launch -> [count][3] dB."""
+        cands = np.ascontiguousarray(cands, np.int32).reshape(-1, 3)
+        out = np.zeros((len(cands), 3), np.float64)
+        self._check(self.lib.ongym_query_gsnr_many(self._h, replica, len(cands), cands.ctypes.data, out.ctypes.data),
+                    "ongym_query_gsnr_many")
+        return out
+
     def candidates(self, row: np.ndarray, nslots: int) -> list:
         """`_get_candidates(row, nslots, len(row))` evaluated on device."""
         row = np.ascontiguousarray(row, np.int32)

@@ -334,6 +334,13 @@ class QRMSAEnv:
         g = self._dev.gsnr(0, int(service.path.id), int(service.initial_slot), int(service.number_slots))
         return float(g[0]), float(g[1]), float(g[2])
 
+    def calculate_osnr_many(self, candidates) -> np.ndarray:
+        """`calculate_osnr` for a list of `(path, initial_slot, number_slots)` candidates in one device launch.
+        Returns float64 [len][3] = (gsnr, ase, nli) dB.  Not in the reference: plugins that score every feasible start
+        (heuristics.py:272-328, 330-416, 647-749) use it instead of one query per candidate."""
+        tri = np.array([(int(p.id), int(s), int(n)) for p, s, n in candidates], np.int32).reshape(-1, 3)
+        return self._dev.gsnr_many(0, tri)
+
     def _allowed_modulations(self):
         M = self.modulations_to_consider
         if self.max_modulation_idx > 1:

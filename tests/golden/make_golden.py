@@ -440,6 +440,119 @@ OBS = {
                                 launch_power_dbm=-1.0),
 }
 
+# ----------------------------------------------------------------------------------------------------------------
+# policy decisions: every listed heuristic is evaluated on the SAME reference state at every step
+# ----------------------------------------------------------------------------------------------------------------
+def _heuristic(name):
+    if name == "psr_c":
+        return lambda env: H.heuristic_psr(env, variant="C")
+    if name == "psr_o":
+        return lambda env: H.heuristic_psr(env, variant="O", coef_dist=0.7, coef_slots=1.3)
+    return getattr(H, name)
+
+
+def run_decisions(tag, topo_name, seed, load, S, warm, steps, driver, observers=(), k=5, bit_rates=(10, 40, 100, 400),
+                  launch_power_dbm=0.0, margin=0.0):
+    """`warm` steps driven by first fit (decisions not recorded), then `steps` steps driven by `driver`; before each of
+    those the `observers` are evaluated on the same state.  An action the env answers with the occupied-slots penalty
+    (request stays current, qrmsa.pyx:886-897; st_retry = 1) or with the QoT ValueError (:925-929; st_retry = 2) is
+    followed by a forced reject so that the run cannot loop forever."""
+    import logging
+    logging.disable(logging.CRITICAL)
+    topo = load_topology(topo_name, k)
+    random.Random = seeded_random(seed)
+    try:
+        env = QRMSAEnvWrapper(
+            topology=topo, seed=10, allow_rejection=True, load=load, episode_length=warm + 2 * steps + 10,
+            num_spectrum_resources=S, launch_power_dbm=launch_power_dbm, bandwidth=S * 12.5e9,
+            frequency_start=3e8 / 1565e-9, frequency_slot_bandwidth=12.5e9, bit_rate_selection="discrete",
+            bit_rates=bit_rates, margin=margin, file_name="", measure_disruptions=False, k_paths=k,
+            modulations_to_consider=6, defragmentation=False, n_defrag_services=0, gen_observation=False)
+    finally:
+        random.Random = _OrigRandom
+    reqs, kinds = [request_tuple(env)], [0]
+    env.reset()
+    reqs.append(request_tuple(env)); kinds.append(0)
+    reject = env.env.reject_action
+    names = [driver] + list(observers)
+    fns = {n: _heuristic(n) for n in names}
+    dec = {n: [] for n in names}
+    rows = []
+    force = False
+    done_steps = 0
+    while done_steps < warm + steps:
+        cur = env.env.current_service
+        if done_steps < warm:
+            action = H.heuristic_shortest_available_path_first_fit_best_modulation(env)[0]
+            forced = 0
+        else:
+            for n in reversed(names):            # the driver is evaluated last
+                a, b, c = fns[n](env)
+                dec[n].append((int(a), int(bool(b)), int(bool(c))))
+            action, forced = dec[driver][-1][0], 0
+            if force:
+                action, forced = reject, 1
+        try:
+            _, reward, done, _, info = env.step(int(action))
+            assert not done
+            retry = int(env.env.current_service is cur)
+        except ValueError as err:                # QoT-infeasible action (qrmsa.pyx:925-929): nothing changed
+            assert "is not enough for service" in str(err) and env.env.current_service is cur
+            reward, retry = 0.0, 2
+        force = bool(retry)
+        rows.append((int(action), forced, retry, 0 if retry else int(cur.accepted), float(reward)))
+        if not retry:
+            reqs.append(request_tuple(env)); kinds.append(1)
+            done_steps += 1
+        elif done_steps < warm:
+            raise AssertionError("first fit produced an occupied action")
+    for n in names:                              # observers were appended in reverse order per step: same length each
+        assert len(dec[n]) == len(dec[driver])
+    reqs_a = np.array(reqs, dtype=np.float64)
+    out = dict(
+        req_at=reqs_a[:, 0].astype(np.float32), req_ht=reqs_a[:, 1].astype(np.float32),
+        req_src=reqs_a[:, 2].astype(np.int32), req_dst=reqs_a[:, 3].astype(np.int32),
+        req_br=reqs_a[:, 4].astype(np.float32), req_kind=np.array(kinds, dtype=np.uint8),
+        st_action=np.array([r[0] for r in rows], np.int32), st_forced=np.array([r[1] for r in rows], np.uint8),
+        st_retry=np.array([r[2] for r in rows], np.uint8), st_accepted=np.array([r[3] for r in rows], np.uint8),
+        st_reward=np.array([r[4] for r in rows], np.float64))
+    for n in names:
+        out["dec_" + n] = np.array(dec[n], np.int32).reshape(-1, 3)
+    meta = dict(tag=tag, topology=topo_name, seed=seed, load=load, S=S, warm=warm, steps=steps, driver=driver,
+                observers=list(observers), k_paths=k, bit_rates=list(bit_rates), launch_power_dbm=launch_power_dbm,
+                margin=margin, bit_rate_selection="discrete", episode_length=warm + 2 * steps + 10, n_rows=len(rows),
+                n_requests=len(reqs), reject_action=int(reject), initial_resets=2)
+    np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **out)
+    json.dump(meta, open(os.path.join(HERE, f"{tag}.json"), "w"), indent=1)
+    d = out["dec_" + driver]
+    print(f"{tag}: {len(rows)} rows, driver {driver}: rejects {(d[:, 0] == reject).sum()}, retries "
+          f"{out['st_retry'].sum()}, accepted {out['st_accepted'][warm:].mean():.3f}; " +
+          ", ".join(f"{n} differs from driver {(out['dec_' + n][:, 0] != d[:, 0]).sum()}x" for n in observers))
+
+
+CHEAP = ("shortest_available_path_lowest_spectrum_best_modulation", "best_modulation_load_balancing",
+         "heuristic_load_balancing_first_fit", "heuristic_mscl_simplified", "heuristic_mscl_sequential_simplified",
+         "psr_c", "psr_o", "heuristic_exact_fit")
+
+DEC = {
+    # heavily loaded NSFNET: resource and QoT blocking both occur
+    "dec_nsfnet320_a": dict(topo_name="nsfnet", seed=101, load=700, S=320, warm=700, steps=300,
+                            driver="shortest_available_path_lowest_spectrum_best_modulation",
+                            observers=CHEAP[1:], launch_power_dbm=1.0),
+    "dec_nsfnet320_b": dict(topo_name="nsfnet", seed=102, load=650, S=320, warm=500, steps=300,
+                            driver="heuristic_mscl_simplified", observers=tuple(n for n in CHEAP if n != "heuristic_mscl_simplified")),
+    "dec_nsfnet320_c": dict(topo_name="nsfnet", seed=103, load=650, S=320, warm=500, steps=300,
+                            driver="heuristic_exact_fit", observers=("best_modulation_load_balancing", "psr_c")),
+    "dec_cost239_d": dict(topo_name="cost239", seed=104, load=900, S=320, warm=900, steps=250,
+                          driver="best_modulation_load_balancing",
+                          observers=("heuristic_load_balancing_first_fit", "heuristic_mscl_sequential_simplified", "psr_o")),
+    # expensive in the reference (every valid start is scored in Python): small grids
+    "dec_nsfnet96_lf": dict(topo_name="nsfnet", seed=105, load=110, S=96, warm=250, steps=90,
+                            driver="heuristic_lowest_fragmentation", bit_rates=(10, 40, 100)),
+    "dec_nsfnet64_mscl": dict(topo_name="nsfnet", seed=106, load=60, S=64, warm=250, steps=100, k=3,
+                              driver="heuristic_mscl", bit_rates=(10, 40, 100)),
+}
+
 TRAJ = {
     "traj_nsfnet320": dict(topo_name="nsfnet", seed=1234, load=300, S=320, episodes=3),
     "traj_nsfnet320_hi": dict(topo_name="nsfnet", seed=77, load=600, S=320, episodes=2,
@@ -480,6 +593,9 @@ def main():
     for tag, kw in OBS.items():
         if not want or tag in want:
             run_observation(tag, **kw)
+    for tag, kw in DEC.items():
+        if not want or tag in want:
+            run_decisions(tag, **kw)
 
 
 if __name__ == "__main__":
