@@ -77,6 +77,9 @@ typedef struct ongym_config {
     int32_t io_device;      /* 1: in/out buffers of step/set_requests calls are device pointers */
     int32_t measure_disruptions; /* qrmsa.pyx:224, 937-952: after every accept re-evaluate the GSNR of the services that share a
                                     link with the new one and count those that fall below their modulation's threshold */
+    int32_t defragmentation;     /* qrmsa.pyx:233, 1117-1119: after a departure, try to move running services to lower slots */
+    int32_t n_defrag_services;   /* qrmsa.pyx:234: 0 = after EVERY departure, no limit on moves; N > 0 = only when the
+                                    episode's request count is a multiple of N, at most N moves */
     double frequency_start;       /* Hz,  qrmsa.pyx:221 */
     double slot_bandwidth;        /* Hz,  qrmsa.pyx:222 */
     double channel_width;         /* GHz, qrmsa.pyx:228 (get_number_slots, qrmsa.pyx:1198-1205) */
@@ -139,7 +142,20 @@ typedef struct ongym_service {
     int16_t modulation;
     int16_t reserved;   /* 1: member of disrupted_services_list (measure_disruptions) */
     float release_time; /* float32(arrival+holding), the heap key after rounding (qrmsa.pyx:1114-1115,1329) */
+    int32_t service_id; /* Service.service_id (qrmsa.pyx:1092); kept only when cfg.defragmentation, else -1 */
+    int32_t pad_;
+    double osnr;        /* Service.OSNR as last written (provisioning or defragment(), qrmsa.pyx:1630); only when
+                           cfg.defragmentation, else 0 */
 } ongym_service;
+
+/* One reallocation done by defragment() (qrmsa.pyx:1590-1635) during the LAST step of a replica: what the compatibility
+ * view needs to update the moved Service object (initial_slot, center_frequency, OSNR, ASE, NLI). */
+#define ONGYM_MOVE_LOG 64
+typedef struct ongym_move {
+    int32_t service_id;
+    int32_t slot;        /* new initial_slot */
+    double osnr, ase, nli; /* dB, as rewritten by defragment() */
+} ongym_move;
 
 /* Counters behind the info dict (qrmsa.pyx:996-1060) and the JOCN per-episode CSV row (graph_load.py:169-186). */
 typedef struct ongym_stats {
@@ -152,13 +168,10 @@ typedef struct ongym_stats {
     double episode_osnr_sum;                                       /* sum of Service.OSNR over the episode's services */
     int64_t episodes_completed;
     int64_t disrupted_services, episode_disrupted_services;       /* qrmsa.pyx:948-952 (both zeroed by reset()) */
-    /* snapshot taken at the last terminal step (what graph_load.py writes per episode) */
-    int64_t last_episode_processed, last_episode_accepted, last_rejected;
-    double last_service_blocking_rate, last_episode_service_blocking_rate;
-    double last_bit_rate_blocking_rate, last_episode_bit_rate_blocking_rate;
-    int64_t last_modulation_hist[8];
-    double last_mean_gsnr;
-    int64_t last_episode_disrupted;
+    /* defragment() (qrmsa.pyx:1545-1639): counters of the current episode, their value when the last step built its info
+     * dict (i.e. before that step's _next_service ran, :1008-1009) */
+    int64_t episode_defrag_cycles, episode_service_reallocations;
+    int64_t step_defrag_cycles, step_service_reallocations;
     /* totals over all completed steps since create (for throughput accounting and the RCCL stats reduction) */
     int64_t total_steps, total_accepted, total_gn_evals, total_interferer_terms;
     int64_t total_paths_tried, total_path_hops; /* candidate paths whose slot rows were read, and their hops */
@@ -166,6 +179,15 @@ typedef struct ongym_stats {
     int64_t total_active_sum;                   /* sum over steps of the running-service count after the step */
     double current_time;
     int32_t active, flags;
+    /* snapshot taken at the last terminal step (what graph_load.py writes per episode). Kept LAST: the kernels hold only
+     * the fields above in LDS and write these straight to memory. */
+    int64_t last_episode_processed, last_episode_accepted, last_rejected;
+    double last_service_blocking_rate, last_episode_service_blocking_rate;
+    double last_bit_rate_blocking_rate, last_episode_bit_rate_blocking_rate;
+    int64_t last_modulation_hist[8];
+    double last_mean_gsnr;
+    int64_t last_episode_disrupted;
+    int64_t last_episode_defrag_cycles, last_episode_service_reallocations;   /* :1008-1009 at the terminal step */
 } ongym_stats;
 
 typedef struct ongym_env ongym_env;
@@ -217,6 +239,9 @@ int ongym_query_candidates(ongym_env *env, const int32_t *row, int32_t total_slo
 /* QRMSAEnv.is_path_free(path, initial_slot, number_slots) (qrmsa.pyx:1248-1264): *out = 1 if free */
 int ongym_query_path_free(ongym_env *env, int32_t replica, int32_t path_id, int32_t slot, int32_t nslots,
                           int32_t *out);
+/* The reallocations defragment() made while the last step of `replica` processed its departures, in order:
+ * out[min(*count, ONGYM_MOVE_LOG)]; *count is the total (entries beyond ONGYM_MOVE_LOG are not kept). */
+int ongym_query_moves(ongym_env *env, int32_t replica, ongym_move *out, int32_t *count);
 /* topology.graph["available_slots"] (qrmsa.pyx:306-309): out[n_links*n_slots] */
 int ongym_query_grid(ongym_env *env, int32_t replica, int32_t *out);
 /* topology.graph["running_services"]: out[capacity], *n = count */

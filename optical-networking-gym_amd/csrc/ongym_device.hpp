@@ -34,7 +34,6 @@ enum RunMode { kModePolicyStep = 0, kModeActionStep = 1, kModePolicyOnly = 2 };
 enum ReqMode { kReqNone = 0, kReqRng = 1, kReqTrace = 2 };
 
 struct DevEnv {
-    ongym_stats st;
     double launch_power, margin, mean_iat;   // per-replica parameters (sweeps as a batch dimension)
     float mean_iat_f, pad1;                  // (float)mean_iat: the sampler works in float32
     uint64_t rng_key;
@@ -42,13 +41,17 @@ struct DevEnv {
     float cur_at, cur_ht, cur_br;            // current_service (C floats in the reference, envs/qrmsa.pyx:35-37)
     int32_t cur_src, cur_dst, cur_id;
     int32_t have_request;                    // _new_service (envs/qrmsa.pyx:1077-1078,1102)
-    float min_rel;                           // unused (kept for layout)
     int32_t pad0;
     // sum of Service.OSNR of the running episode = osnr_flushed - 10 log10(osnr_prod): the product takes one multiply per
     // accepted service and one log10 per ~60 of them; both survive across launches so results do not depend on how
     // the steps are partitioned into launches. st.episode_osnr_sum is refreshed from them at every store.
     double osnr_flushed, osnr_prod;
+    ongym_stats st;                          // LAST: its tail (the terminal-step snapshot) never enters LDS
 };
+// The kernels keep DevEnv up to (not including) st.last_episode_processed in LDS; the snapshot fields behind it are
+// written to memory directly by snapshot_terminal.
+constexpr size_t kEnvHotBytes = (offsetof(DevEnv, st) + offsetof(ongym_stats, last_episode_processed) + 7) & ~(size_t)7;
+static_assert(offsetof(DevEnv, st) % 8 == 0, "DevEnv.st must be 8-byte aligned");
 
 struct Params {
     int n_nodes, n_links, n_paths, k_paths, max_hops, n_mods, n_slots;
@@ -57,6 +60,7 @@ struct Params {
     int batch, capacity, episode_length, auto_reset;
     int bit_rate_mode, n_bit_rates, br_lo, br_hi;
     int measure_disruptions;
+    int defragmentation, n_defrag_services;   // envs/qrmsa.pyx:233-234
     int uniform_alpha;
     int rec32;          // record codec R32 in use (n_links <= 32, n_paths <= 512)
     int ase_shortcut;   // 1: every interferer term of the NLI sum is provably >= 0 (checked on the host at create)
@@ -91,6 +95,10 @@ struct Params {
     uint64_t *occ;
     uint32_t *svc_a, *svc_b;
     float *svc_r;
+    uint32_t *svc_q;   // Service.service_id per record  } only when defragmentation
+    double *svc_o;     // Service.OSNR per record        }
+    ongym_move *move_log;   // [batch][ONGYM_MOVE_LOG] reallocations of the last step   } only when defragmentation
+    int32_t *move_n;        // [batch] their count                                       }
     DevEnv *env;
     // request trace (req_mode == kReqTrace)
     const ongym_request *trace;
@@ -101,13 +109,21 @@ struct Params {
 // ---------------------------------------------------------------------------------------------------------------
 // LDS carve-up (dynamic shared memory), 8-byte aligned pieces first
 //   occ u64[E*W] | lw1 f64[E] | lw2 f64[E] | lcl f64[E] | lsc f64[E] | DevEnv | sa u32[C] | sb u32[C] | sr f32[C] |
-//   lim f64[8] | rp f64[2] | phi f64[8] | nreq i32[8] | list u16[C] | (lim0 f64[8] when measure_disruptions)
+//   lim f64[8] | rp f64[2] | phi f64[8] | nreq i32[8] | list u16[C] |
+//   (lim0 f64[8] when measure_disruptions or defragmentation) | (so f64[C] | sq u32[C] when defragmentation)
+// (DevEnv = its first kEnvHotBytes)
 // ---------------------------------------------------------------------------------------------------------------
 __host__ __device__ inline size_t lds_bytes(int n_links, int row_words, int capacity, int uniform_alpha,
-                                            int measure_disruptions = 0) {
-    size_t b = (size_t)n_links * row_words * 8 + (size_t)n_links * (uniform_alpha ? 16 : 32) + ((sizeof(DevEnv) + 7) & ~(size_t)7);
-    b += (size_t)capacity * 12 + 64 + 16 + 64 + 32 + (size_t)capacity * 2 + (measure_disruptions ? 64 : 0);
+                                            int measure_disruptions, int defragmentation) {
+    size_t b = (size_t)n_links * row_words * 8 + (size_t)n_links * (uniform_alpha ? 16 : 32) + kEnvHotBytes;
+    b += (size_t)capacity * 12 + 64 + 16 + 64 + 32 + (size_t)capacity * 2;
+    b += (measure_disruptions || defragmentation) ? 64 : 0;
+    b += defragmentation ? (size_t)capacity * 12 : 0;
     return (b + 15) & ~(size_t)15;
+}
+
+__host__ __device__ inline size_t lds_bytes(const Params &P) {
+    return lds_bytes(P.n_links, P.row_words, P.capacity, P.uniform_alpha, P.measure_disruptions, P.defragmentation);
 }
 
 #ifdef ONGYM_STAMPS
@@ -143,6 +159,8 @@ struct Ctx {
     double *lim;       // LDS [8] linear-domain acceptance limits 10^(-(thr_m+margin)/10) of this replica
     double *rp;        // LDS [2] 1/launch_power, launch_power^2 of this replica
     double *lim0;      // LDS [8] 10^(-thr_m/10): the disruption check ignores the margin (envs/qrmsa.pyx:947)
+    double *so;        // LDS [C] Service.OSNR per record        } defragmentation only
+    uint32_t *sq;      // LDS [C] Service.service_id per record  }
     double *phi;       // LDS [8] Phi_mod * 5/3 per modulation
     uint16_t *list;
     double node_cum_reg;   // node_cum[lane] (+inf beyond n_nodes) when n_nodes <= 64
@@ -173,7 +191,7 @@ __device__ __forceinline__ void ctx_bind(Ctx &c, unsigned char *smem) {
     c.lcl = c.lw2 + P.n_links;
     c.lsc = c.lcl + (P.uniform_alpha ? 0 : P.n_links);
     c.e = reinterpret_cast<DevEnv *>(c.lsc + (P.uniform_alpha ? 0 : P.n_links));
-    c.sa = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(c.e) + ((sizeof(DevEnv) + 7) & ~(size_t)7));
+    c.sa = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(c.e) + kEnvHotBytes);
     c.sb = c.sa + P.capacity;
     c.sr = reinterpret_cast<float *>(c.sb + P.capacity);
     c.lim = reinterpret_cast<double *>(c.sr + P.capacity);   // capacity is a multiple of 64 -> 8-byte aligned
@@ -182,6 +200,8 @@ __device__ __forceinline__ void ctx_bind(Ctx &c, unsigned char *smem) {
     c.nreq = reinterpret_cast<int *>(c.phi + 8);
     c.list = reinterpret_cast<uint16_t *>(c.nreq + 8);
     c.lim0 = reinterpret_cast<double *>(c.list + P.capacity);   // capacity % 64 == 0 -> 8-byte aligned; only if enabled
+    c.so = c.lim0 + 8;                                          // only with defragmentation
+    c.sq = reinterpret_cast<uint32_t *>(c.so + P.capacity);
 }
 
 // Table pointers live in a Params object read from memory, so the compiler cannot know they are global and would emit
@@ -788,6 +808,7 @@ __device__ __forceinline__ void reset_env(Ctx &c) {
         for (int m = 0; m < 8; m++) s.episode_modulation_hist[m] = 0;
         s.bit_rate_requested = 0.0; s.bit_rate_provisioned = 0.0;   // :466-467
         s.disrupted_services = 0; s.episode_disrupted_services = 0;   // :432, 468-469
+        s.episode_defrag_cycles = 0; s.episode_service_reallocations = 0;   // :438-439
         s.episode_osnr_sum = 0.0;
         e->osnr_flushed = 0.0; c.osnr_prod = 1.0;
         e->have_request = 0;
@@ -796,22 +817,28 @@ __device__ __forceinline__ void reset_env(Ctx &c) {
     draw_next(c);   // no departures possible: the network is empty
 }
 
-__device__ __forceinline__ void snapshot_terminal(DevEnv *e) {   // info of the terminal step, envs/qrmsa.pyx:996-1060
-    ongym_stats &s = e->st;
-    s.last_episode_processed = s.episode_services_processed; s.last_episode_accepted = s.episode_services_accepted;
-    s.last_rejected = s.rejected;
-    s.last_service_blocking_rate = s.services_processed > 0
+// info of the terminal step (envs/qrmsa.pyx:996-1060), lane 0 only. Source: the LDS copy; destination: the snapshot
+// fields of the replica's DevEnv in memory (they are not part of the LDS image).
+__device__ __forceinline__ void snapshot_terminal(Ctx &c) {
+    const DevEnv *e = c.e;
+    const ongym_stats &s = e->st;
+    ongym_stats &o = c.P.env[c.replica].st;
+    o.last_episode_processed = s.episode_services_processed; o.last_episode_accepted = s.episode_services_accepted;
+    o.last_rejected = s.rejected;
+    o.last_service_blocking_rate = s.services_processed > 0
         ? (double)(s.services_processed - s.services_accepted) / (double)s.services_processed : 0.0;
-    s.last_episode_service_blocking_rate = s.episode_services_processed > 0
+    o.last_episode_service_blocking_rate = s.episode_services_processed > 0
         ? (double)(s.episode_services_processed - s.episode_services_accepted) / (double)s.episode_services_processed : 0.0;
-    s.last_bit_rate_blocking_rate = s.bit_rate_requested > 0
+    o.last_bit_rate_blocking_rate = s.bit_rate_requested > 0
         ? (s.bit_rate_requested - s.bit_rate_provisioned) / s.bit_rate_requested : 0.0;
-    s.last_episode_bit_rate_blocking_rate = s.episode_bit_rate_requested > 0
+    o.last_episode_bit_rate_blocking_rate = s.episode_bit_rate_requested > 0
         ? (s.episode_bit_rate_requested - s.episode_bit_rate_provisioned) / s.episode_bit_rate_requested : 0.0;
-    for (int m = 0; m < 8; m++) s.last_modulation_hist[m] = s.episode_modulation_hist[m];
+    for (int m = 0; m < 8; m++) o.last_modulation_hist[m] = s.episode_modulation_hist[m];
     // graph_load.py:181-185: mean of Service.OSNR over topology.graph["services"] (one entry per completed step)
-    s.last_mean_gsnr = s.episode_services_processed > 0 ? e->osnr_flushed / (double)s.episode_services_processed : 0.0;
-    s.last_episode_disrupted = s.episode_disrupted_services;
+    o.last_mean_gsnr = s.episode_services_processed > 0 ? e->osnr_flushed / (double)s.episode_services_processed : 0.0;
+    o.last_episode_disrupted = s.episode_disrupted_services;
+    o.last_episode_defrag_cycles = s.episode_defrag_cycles;
+    o.last_episode_service_reallocations = s.episode_service_reallocations;
 }
 
 
@@ -820,9 +847,62 @@ __device__ __forceinline__ void snapshot_terminal(DevEnv *e) {   // info of the 
 // running lists) and is not yet in the disrupted list gets its GSNR re-evaluated against all other running services; below
 // its modulation's minimum_osnr (no margin) it joins the list. The list membership is the sign bit of the record's
 // release time. Per measured service one pass over the whole service table (lanes over records).
+// 1/GSNR (linear) of the RUNNING service in record iy, evaluated as if it sat at slot `sy` (its own slot, or a slot
+// defragment() wants to move it to), against every other running service: itself is skipped like the service_id test
+// of core/osnr.pyx:65. One pass over the whole service table, lanes over records. Uniform attenuation only.
+template <bool R32>
+__device__ __forceinline__ GnLin gn_service_acc(Ctx &c, int iy, int py, int sy, int ny) {
+    const Params &P = c.P;
+    uint64_t ym0, ym1;
+    if (R32) { ym0 = c.sa[iy]; ym1 = 0; } else { ym0 = G(P.path_mask)[2 * py]; ym1 = G(P.path_mask)[2 * py + 1]; }
+    const int c2 = 2 * sy + ny;
+    double part = 0.0;
+    for (int base = 0; base < c.active; base += kWave) {
+        const int iz = base + c.lane;
+        if (iz >= c.active || iz == iy) continue;
+        const uint32_t a = c.sa[iz], b = c.sb[iz];
+        uint64_t m0, m1;
+        if (R32) { m0 = a & (uint32_t)ym0; m1 = 0; }
+        else { int pk = a & 0xFFFF; m0 = G(P.path_mask)[2 * pk] & ym0; m1 = G(P.path_mask)[2 * pk + 1] & ym1; }
+        if (!(m0 | m1)) continue;
+        const int sk = rec_slot<R32>(a, b), nk = rec_n<R32>(a, b), mk = rec_mod<R32>(a, b);
+        const int adi = abs((2 * sk + nk) - c2);
+        double A, corr;
+        if (nk <= P.tab_nmax) {
+            const auto *t = G(reinterpret_cast<const double *>(P.pair_tab)) + 2 * ((nk - 1) * P.tab_stride + adi);
+            A = t[0]; corr = c.phi[mk] * t[1];
+        } else {
+            double bk = P.slot_bw * nk, adf = (0.5 * P.slot_bw) * (double)adi, ck = P.alpha0_cl * bk;
+            A = asinh_diff(ck * (adf + 0.5 * bk), ck * (adf - 0.5 * bk));
+            corr = c.phi[mk] * (bk / adf);
+        }
+        double w1 = 0.0, w2 = 0.0;
+        while (m0) { int l = __ffsll((unsigned long long)m0) - 1; m0 &= m0 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
+        while (m1) { int l = 64 + __ffsll((unsigned long long)m1) - 1; m1 &= m1 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
+        part += A * w1 - corr * w2;
+    }
+    if (c.lane == 0) part += G(P.path_w1)[py] * G(P.self_asinh)[ny];
+    const double total = wave_sum(part);
+    const double bw = P.slot_bw * ny;
+    const double fc = P.f0 + (P.slot_bw * sy) + (P.slot_bw * (ny / 2.0));
+    GnLin g;
+    g.ase = (bw * fc * G(P.path_ase)[py]) * c.rp[0];
+    g.nli = (G(P.nli_coef)[ny] * c.rp[1]) * total;
+    return g;
+}
+
+// GSNR < minimum_osnr of modulation `my` (no margin)?  Linear-domain compare with the dB fallback band of qot_ok.
+__device__ __forceinline__ int below_minimum_osnr(const Ctx &c, double acc, int my) {
+    const double lim = c.lim0[my];
+    int below;
+    if (acc >= lim * (1.0 + 1e-9)) below = 1;
+    else if (acc <= lim * (1.0 - 1e-9)) below = 0;
+    else below = 10.0 * log10(1.0 / acc) < c.P.mod_thr[my];
+    return uniform_i32(below);
+}
+
 template <bool R32>
 __device__ __forceinline__ int measure_disruptions(Ctx &c, uint64_t nm0, uint64_t nm1) {
-    const Params &P = c.P;
     const int L = gn_build_list<R32>(c, nm0, nm1);          // services on the new service's links
     int newly = 0;
     for (int j = 0; j < L; j++) {
@@ -832,45 +912,8 @@ __device__ __forceinline__ int measure_disruptions(Ctx &c, uint64_t nm0, uint64_
         const uint32_t ay = c.sa[iy], by = c.sb[iy];
         const int py = uniform_i32(rec_path<R32>(ay, by)), sy = uniform_i32(rec_slot<R32>(ay, by));
         const int ny = uniform_i32(rec_n<R32>(ay, by)), my = uniform_i32(rec_mod<R32>(ay, by));
-        uint64_t ym0, ym1;
-        if (R32) { ym0 = ay; ym1 = 0; } else { ym0 = G(P.path_mask)[2 * py]; ym1 = G(P.path_mask)[2 * py + 1]; }
-        const int c2 = 2 * sy + ny;
-        double part = 0.0;
-        for (int base = 0; base < c.active; base += kWave) {
-            const int iz = base + c.lane;
-            if (iz >= c.active || iz == iy) continue;        // itself excluded (service_id test of core/osnr.pyx:65)
-            const uint32_t a = c.sa[iz], b = c.sb[iz];
-            uint64_t m0, m1;
-            if (R32) { m0 = a & (uint32_t)ym0; m1 = 0; }
-            else { int pk = a & 0xFFFF; m0 = G(P.path_mask)[2 * pk] & ym0; m1 = G(P.path_mask)[2 * pk + 1] & ym1; }
-            if (!(m0 | m1)) continue;
-            const int sk = rec_slot<R32>(a, b), nk = rec_n<R32>(a, b), mk = rec_mod<R32>(a, b);
-            const int adi = abs((2 * sk + nk) - c2);
-            double A, corr;
-            if (nk <= P.tab_nmax) {
-                const auto *t = G(reinterpret_cast<const double *>(P.pair_tab)) + 2 * ((nk - 1) * P.tab_stride + adi);
-                A = t[0]; corr = c.phi[mk] * t[1];
-            } else {
-                double bk = P.slot_bw * nk, adf = (0.5 * P.slot_bw) * (double)adi, ck = P.alpha0_cl * bk;
-                A = asinh_diff(ck * (adf + 0.5 * bk), ck * (adf - 0.5 * bk));
-                corr = c.phi[mk] * (bk / adf);
-            }
-            double w1 = 0.0, w2 = 0.0;
-            while (m0) { int l = __ffsll((unsigned long long)m0) - 1; m0 &= m0 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
-            while (m1) { int l = 64 + __ffsll((unsigned long long)m1) - 1; m1 &= m1 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
-            part += A * w1 - corr * w2;
-        }
-        if (c.lane == 0) part += G(P.path_w1)[py] * G(P.self_asinh)[ny];
-        const double total = wave_sum(part);
-        const double bw = P.slot_bw * ny;
-        const double fc = P.f0 + (P.slot_bw * sy) + (P.slot_bw * (ny / 2.0));
-        const double acc = (bw * fc * G(P.path_ase)[py]) * c.rp[0] + (G(P.nli_coef)[ny] * c.rp[1]) * total;
-        const double lim = c.lim0[my];
-        int below;                                            // osnr_svc < minimum_osnr ?
-        if (acc >= lim * (1.0 + 1e-9)) below = 1;
-        else if (acc <= lim * (1.0 - 1e-9)) below = 0;
-        else below = 10.0 * log10(1.0 / acc) < P.mod_thr[my];
-        if (uniform_i32(below)) {
+        const GnLin g = gn_service_acc<R32>(c, iy, py, sy, ny);
+        if (below_minimum_osnr(c, g.ase + g.nli, my)) {      // osnr_svc < minimum_osnr (envs/qrmsa.pyx:947)
             if (c.lane == 0) c.sr[iy] = -ry;
             newly++;
         }
@@ -879,9 +922,130 @@ __device__ __forceinline__ int measure_disruptions(Ctx &c, uint64_t nm0, uint64_
     return newly;
 }
 
+// ---- defragment (envs/qrmsa.pyx:1545-1639) ----------------------------------------------------------------------------
+// Running services in the order of topology.graph["running_services"] (= ascending service_id: appended when
+// provisioned, never reordered). Each is offered the valid starts of its own path for its own slot count, lowest first,
+// below its present slot (its own slots still count as occupied); the first whose GSNR - service moved there, itself
+// excluded - is not below minimum_osnr (no margin) is taken: old [slot, slot+n+1) freed (clamped at S), new
+// [start, start+n (+1 unless it ends at S)) occupied, Service.OSNR rewritten (it feeds the episode's mean GSNR).
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        uint64_t o = __shfl_xor((unsigned long long)v, m);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+template <bool R32>
+__device__ __forceinline__ void defragment(Ctx &c, int num_services) {
+    const Params &P = c.P;
+    DevEnv *e = c.e;
+    if (c.lane == 0) e->st.episode_defrag_cycles += 1;
+    if (num_services == 0) num_services = 1000000;
+    int moved = 0;
+    long long last = -1;
+    for (;;) {
+        if (moved >= num_services) break;
+        uint64_t key = ~0ull;                                 // (service_id << 16) | record index, smallest id above `last`
+        for (int i = c.lane; i < c.active; i += kWave) {
+            const uint64_t q = c.sq[i];
+            if ((long long)q > last) { const uint64_t k = (q << 16) | (uint64_t)i; key = k < key ? k : key; }
+        }
+        key = wave_min_u64(key);
+        if (key == ~0ull) break;
+        const int iy = (int)(key & 0xFFFF);
+        last = (long long)(key >> 16);
+        const uint32_t ay = c.sa[iy], by = c.sb[iy];
+        const int py = uniform_i32(rec_path<R32>(ay, by)), sy = uniform_i32(rec_slot<R32>(ay, by));
+        const int ny = uniform_i32(rec_n<R32>(ay, by)), my = uniform_i32(rec_mod<R32>(ay, by));
+        if (sy == 0) continue;
+        const PathRef p = load_path(c, py);
+        int rr = 1;
+        uint64_t v = run_and(path_free_ext(c, p), rr, ny + 1);   // _get_candidates(available, n, S)
+        v &= word_range(c.lane, 0, sy);                          // candidate >= initial_slot: skipped (:1583-1584)
+        int target = -1;
+        GnLin g;
+        g.ase = g.nli = 0.0;
+        for (;;) {
+            const int s0 = first_set(v);
+            if (s0 < 0) break;
+            g = gn_service_acc<R32>(c, iy, py, s0, ny);
+            if (!below_minimum_osnr(c, g.ase + g.nli, my)) { target = s0; break; }
+            if (c.lane == (s0 >> 6)) v &= ~(1ull << (s0 & 63));
+        }
+        if (target < 0) continue;
+        __syncthreads();
+        mark_links(c, p.hops, p.mylink, sy, sy + ny + 1, true);
+        int end = target + ny; if (end < P.n_slots) end += 1;
+        mark_links(c, p.hops, p.mylink, target, end, false);
+        if (c.lane == 0) {
+            uint32_t ra, rb;
+            rec_pack<R32>(py, p.m0, target, ny, my, ra, rb);
+            c.sa[iy] = ra; c.sb[iy] = rb;
+            const double osnr = -10.0 * log10(g.ase + g.nli);
+            e->osnr_flushed += osnr - c.so[iy];              // the Service object in topology.graph["services"] is updated
+            c.so[iy] = osnr;
+            e->st.episode_service_reallocations += 1;
+            const int nlog = P.move_n[c.replica];            // what the compatibility view replays onto its Service objects
+            if (nlog < ONGYM_MOVE_LOG) {
+                ongym_move mv;
+                mv.service_id = (int32_t)c.sq[iy]; mv.slot = target;
+                mv.osnr = osnr; mv.ase = -10.0 * log10(g.ase); mv.nli = -10.0 * log10(g.nli);
+                P.move_log[(size_t)c.replica * ONGYM_MOVE_LOG + nlog] = mv;
+            }
+            P.move_n[c.replica] = nlog + 1;
+        }
+        moved++;
+        __syncthreads();
+    }
+}
+
+// Departures with defragmentation (envs/qrmsa.pyx:1113-1122): the due services leave one at a time in heap order
+// (release time, then service_id), and defragment() may run after each of them. Release times are kept as float32
+// (the reference compares them as `cdef float`); two due services whose double keys differ but round to the same float32
+// are ordered by service_id here.
+template <bool R32>
+__device__ __forceinline__ void release_due_defrag(Ctx &c, float now) {
+    const Params &P = c.P;
+    for (;;) {
+        uint64_t key = ~0ull;                                 // (float bits of the release time << 32) | service_id
+        int mine = -1;
+        for (int i = c.lane; i < c.active; i += kWave) {
+            const float r = fabsf(c.sr[i]);
+            if (r <= now) {
+                const uint64_t k = ((uint64_t)__float_as_uint(r) << 32) | (uint64_t)c.sq[i];
+                if (k < key) { key = k; mine = i; }
+            }
+        }
+        const uint64_t best = wave_min_u64(key);
+        if (best == ~0ull) break;
+        const uint64_t bal = __ballot(key == best);
+        const int idx = __builtin_amdgcn_readlane(mine, __ffsll((unsigned long long)bal) - 1);
+        const uint32_t a = c.sa[idx], b = c.sb[idx];
+        const int sk = rec_slot<R32>(a, b), nk = rec_n<R32>(a, b);
+        if (R32) mark_mask(c, a, sk, sk + nk + 1, true);
+        else {
+            const int pk = a & 0xFFFF;
+            const int hops = G(P.path_hops)[pk];
+            const int mylink = (c.lane < hops) ? G(P.path_links)[pk * P.max_hops + c.lane] : 0;
+            mark_links(c, hops, mylink, sk, sk + nk + 1, true);
+        }
+        const int lastrec = c.active - 1;
+        if (c.lane == 0 && idx != lastrec) {
+            c.sa[idx] = c.sa[lastrec]; c.sb[idx] = c.sb[lastrec]; c.sr[idx] = c.sr[lastrec];
+            c.sq[idx] = c.sq[lastrec]; c.so[idx] = c.so[lastrec];
+        }
+        c.active = lastrec;
+        __syncthreads();
+        if (P.n_defrag_services == 0 || c.e->st.episode_services_processed % P.n_defrag_services == 0)
+            defragment<R32>(c, P.n_defrag_services);
+    }
+}
+
 // ---- one request: apply the choice (envs/qrmsa.pyx:838-1065) ----------------------------------------------------
 // outcome: 0 = accept & provision, 1 = reject action, 2 = retry (slots busy), 3 = QoT error
-template <bool R32>
+template <bool R32, bool DEFRAG>
 __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome, ongym_step_rec *rec) {
     const Params &P = c.P;
     DevEnv *e = c.e;
@@ -926,8 +1090,15 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
             // graph_load.py:181-185) accumulates the product of the acc's and takes one log10 per ~60 services
             double g[3] = {0.0, 0.0, 0.0};
             if (rec) { g[0] = -10.0 * log10(ch.g.ase + ch.g.nli); g[1] = -10.0 * log10(ch.g.ase); g[2] = -10.0 * log10(ch.g.nli); }
-            c.osnr_prod *= (ch.g.ase + ch.g.nli);
-            if (c.osnr_prod < 1e-250) flush_osnr(c);
+            if (DEFRAG) {   // defragment() rewrites Service.OSNR of the services it moves: keep it per record, sum it directly
+                if (!rec) g[0] = -10.0 * log10(ch.g.ase + ch.g.nli);
+                e->osnr_flushed += g[0];
+                c.so[c.active] = g[0];
+                c.sq[c.active] = (uint32_t)(s.episode_services_processed - 1);   // Service.service_id (:1092)
+            } else {
+                c.osnr_prod *= (ch.g.ase + ch.g.nli);
+                if (c.osnr_prod < 1e-250) flush_osnr(c);
+            }
             rel = e->cur_at + e->cur_ht;   // float + float (:1329); compared as float32 (:1114-1115)
             uint32_t ra, rb;
             rec_pack<R32>(ch.path, ch.m0, ch.slot, ch.n, ch.mod, ra, rb);
@@ -950,9 +1121,13 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
         }
         s.total_steps += 1;
         e->have_request = 0;
+        if (DEFRAG) {   // info["episode_defrag_cicles"], info["episode_service_realocations"] (:1008-1009)
+            s.step_defrag_cycles = s.episode_defrag_cycles; s.step_service_reallocations = s.episode_service_reallocations;
+            P.move_n[c.replica] = 0;
+        }
         // the info dict is computed before the next request is drawn (:996-1050); the step terminates the episode
         // iff that draw makes episode_services_processed reach episode_length (:1056)
-        if (s.episode_services_processed + 1 == P.episode_length) { flush_osnr(c); snapshot_terminal(e); }
+        if (s.episode_services_processed + 1 == P.episode_length) { flush_osnr(c); snapshot_terminal(c); }
         if (rec) *rec = r;
     }
     if (outcome == 0) {
@@ -966,11 +1141,16 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
     }
     draw_next(c);                                 // first half of _next_service (:1079-1111)
     STAMP(c, 6);
-    release_due<R32>(c, e->cur_at);               // second half of _next_service (:1113-1122)
+    if (DEFRAG) release_due_defrag<R32>(c, e->cur_at);
+    else release_due<R32>(c, e->cur_at);          // second half of _next_service (:1113-1122)
     STAMP(c, 7);
     int terminated = e->st.episode_services_processed == P.episode_length;
     if (c.lane == 0) {
         if (terminated) e->st.episodes_completed += 1;
+        // graph_load.py:181-185 reads Service.OSNR after the loop, i.e. after the departures (and moves) of this
+        // _next_service
+        if (DEFRAG && terminated)
+            P.env[c.replica].st.last_mean_gsnr = e->osnr_flushed / (double)(e->st.episode_services_processed - 1);
         if (rec) { rec->active = c.active; rec->terminated = (uint8_t)terminated; }
     }
     c.active_sum += c.active;
@@ -1322,7 +1502,7 @@ __device__ __forceinline__ void load_state(Ctx &c) {
     // DevEnv: 8-byte words by lanes
     const uint64_t *ge = reinterpret_cast<const uint64_t *>(P.env + c.replica);
     uint64_t *le = reinterpret_cast<uint64_t *>(c.e);
-    for (int i = c.lane; i < (int)(sizeof(DevEnv) / 8); i += kWave) le[i] = ge[i];
+    for (int i = c.lane; i < (int)(kEnvHotBytes / 8); i += kWave) le[i] = ge[i];
     for (int i = c.lane; i < P.n_links; i += kWave) {
         c.lw1[i] = P.link_w1[i]; c.lw2[i] = P.link_w2[i];
         if (!P.uniform_alpha) { c.lcl[i] = P.link_cl[i]; c.lsc[i] = P.link_selfc[i]; }
@@ -1341,7 +1521,7 @@ __device__ __forceinline__ void load_state(Ctx &c) {
     if (c.e->have_request) prefetch_first_path(c, c.e->cur_src, c.e->cur_dst);
     // per-replica acceptance limits in the linear domain (see qot_ok)
     if (c.lane < P.n_mods) c.lim[c.lane] = pow(10.0, -(P.mod_thr[c.lane] + c.e->margin) / 10.0);
-    if (P.measure_disruptions && c.lane < P.n_mods) c.lim0[c.lane] = pow(10.0, -P.mod_thr[c.lane] / 10.0);
+    if ((P.measure_disruptions || P.defragmentation) && c.lane < P.n_mods) c.lim0[c.lane] = pow(10.0, -P.mod_thr[c.lane] / 10.0);
     if (c.lane < kMaxMods) c.phi[c.lane] = c.lane < P.n_mods ? P.mod_phi53[c.lane] : 0.0;
     if (c.lane == 0) { c.rp[0] = 1.0 / c.e->launch_power; c.rp[1] = c.e->launch_power * c.e->launch_power; }
     // slots needed by the current request (kept in LDS between requests, recomputed on load)
@@ -1349,6 +1529,8 @@ __device__ __forceinline__ void load_state(Ctx &c) {
         c.nreq[c.lane] = (int)ceil((double)c.e->cur_br / ((double)P.mod_se[c.lane] * P.channel_width));
     size_t off = (size_t)c.replica * P.capacity;
     for (int i = c.lane; i < c.active; i += kWave) { c.sa[i] = P.svc_a[off + i]; c.sb[i] = P.svc_b[off + i]; c.sr[i] = P.svc_r[off + i]; }
+    if (P.defragmentation)
+        for (int i = c.lane; i < c.active; i += kWave) { c.sq[i] = P.svc_q[off + i]; c.so[i] = P.svc_o[off + i]; }
     __syncthreads();
 }
 
@@ -1371,12 +1553,14 @@ __device__ __forceinline__ void store_state(Ctx &c) {
     __syncthreads();
     uint64_t *ge = reinterpret_cast<uint64_t *>(P.env + c.replica);
     const uint64_t *le = reinterpret_cast<const uint64_t *>(c.e);
-    for (int i = c.lane; i < (int)(sizeof(DevEnv) / 8); i += kWave) ge[i] = le[i];
+    for (int i = c.lane; i < (int)(kEnvHotBytes / 8); i += kWave) ge[i] = le[i];
     int words = P.n_links * P.row_words;
     uint64_t *g = P.occ + (size_t)c.replica * words;
     for (int i = c.lane; i < words; i += kWave) g[i] = c.occ[i];
     size_t off = (size_t)c.replica * P.capacity;
     for (int i = c.lane; i < c.active; i += kWave) { P.svc_a[off + i] = c.sa[i]; P.svc_b[off + i] = c.sb[i]; P.svc_r[off + i] = c.sr[i]; }
+    if (P.defragmentation)
+        for (int i = c.lane; i < c.active; i += kWave) { P.svc_q[off + i] = c.sq[i]; P.svc_o[off + i] = c.so[i]; }
 }
 
 }  // namespace ongym

@@ -18,7 +18,7 @@ using namespace ongym;
 // ---------------------------------------------------------------------------------------------------------------
 // WAVES = waves per SIMD the register allocation is bounded for: 5 when the replica's LDS block is <= 8 KiB (20 replicas
 // per CU), else 4
-template <bool UA, bool R32, int WAVES, int POLICY>
+template <bool UA, bool R32, int WAVES, int POLICY, bool DEFRAG = false>
 __global__ __launch_bounds__(64, WAVES) void k_run(const Params *__restrict__ Pp, int mode, int nsteps, const int32_t *actions, int32_t *act_out,
                                             uint8_t *flag_out, ongym_step_rec *out) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(64, WAVES) void k_run(const Params *__restrict__ Pp
     c.stamp_last = __builtin_amdgcn_s_memtime();
 #endif
     if (POLICY == ONGYM_POLICY_HIGHEST_SNR) {   // extra LDS: Fx f64[2S+2] | Vw u64[8*16] | xlist u16[2S+2] | needx u8[2S+2]
-        c.fl.Fx = reinterpret_cast<double *>(smem + lds_bytes(P.n_links, P.row_words, P.capacity, P.uniform_alpha, P.measure_disruptions));
+        c.fl.Fx = reinterpret_cast<double *>(smem + lds_bytes(P));
         c.fl.Vw = reinterpret_cast<uint64_t *>(c.fl.Fx + 2 * P.n_slots + 2);
         c.fl.xlist = reinterpret_cast<uint16_t *>(c.fl.Vw + kMaxMods * kMaxRowWords);
         c.fl.needx = reinterpret_cast<uint8_t *>(c.fl.xlist + 2 * P.n_slots + 2);
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64, WAVES) void k_run(const Params *__restrict__ Pp
             if (c.lane == 0) { act_out[c.replica] = ch.action; if (flag_out) flag_out[c.replica] = (uint8_t)ch.flags; }
             continue;
         }
-        apply_step<R32>(c, ch, outcome, rec);
+        apply_step<R32, DEFRAG>(c, ch, outcome, rec);
     }
     if (mode != kModePolicyOnly) store_state(c);
     STAMP(c, 9);
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64) void k_observe(const Params *__restrict__ Pp, f
     c.paths_tried = 0; c.path_hops = 0; c.active_sum = 0;
     ctx_bind(c, smem);
     load_state(c);
-    double *Fx = reinterpret_cast<double *>(smem + lds_bytes(P.n_links, P.row_words, P.capacity, P.uniform_alpha, P.measure_disruptions));
+    double *Fx = reinterpret_cast<double *>(smem + lds_bytes(P));
     const size_t obs_dim = 3 + P.k_paths + (size_t)P.k_paths * P.n_mods * 12;
     const size_t nact = (size_t)P.k_paths * P.n_mods * P.n_slots + 1;
     // extra LDS of the observation kernel: Fx f64[2S+2] | Vw u64[8*16] | xlist u16[2S+2] | needx u8[2S+2]
@@ -208,6 +208,8 @@ __global__ __launch_bounds__(64) void k_query(const Params *__restrict__ Pp, int
             o[i].nslots = (int16_t)rec_n<R32>(a, b); o[i].modulation = (int16_t)rec_mod<R32>(a, b);
             o[i].reserved = c.sr[i] < 0.f ? 1 : 0;   // 1: in the disrupted list (measure_disruptions)
             o[i].release_time = fabsf(c.sr[i]);
+            o[i].service_id = P.defragmentation ? (int32_t)c.sq[i] : -1; o[i].pad_ = 0;
+            o[i].osnr = P.defragmentation ? c.so[i] : 0.0;
         }
     } else if (what == kQCandidates) {  // _get_candidates on a caller-supplied row: path = total_slots, n = nslots
         const int total = path;
@@ -343,6 +345,9 @@ static int build(ongym_env *env, const ongym_config *c) {
     P.bit_rate_mode = c->bit_rate_mode; P.n_bit_rates = c->n_bit_rates; P.br_lo = c->bit_rate_lo; P.br_hi = c->bit_rate_hi;
     P.req_mode = kReqNone;
     P.measure_disruptions = c->measure_disruptions ? 1 : 0;
+    P.defragmentation = c->defragmentation ? 1 : 0;
+    P.n_defrag_services = c->n_defrag_services;
+    if (c->defragmentation && c->n_defrag_services < 0) return fail_arg(env, "n_defrag_services must be >= 0");
     P.f0 = c->frequency_start; P.slot_bw = c->slot_bandwidth; P.channel_width = c->channel_width;
     P.mean_holding = c->mean_holding_time;
     P.max_bit_rate = c->max_bit_rate;
@@ -365,6 +370,8 @@ static int build(ongym_env *env, const ongym_config *c) {
     }
     P.uniform_alpha = uniform ? 1 : 0;
     if (c->measure_disruptions && !uniform) return fail_arg(env, "measure_disruptions needs uniform attenuation", ONGYM_E_LIMIT);
+    if (c->defragmentation && !uniform) return fail_arg(env, "defragmentation needs uniform attenuation", ONGYM_E_LIMIT);
+    if (c->defragmentation && c->capacity > 65535) return fail_arg(env, "defragmentation needs capacity <= 65535", ONGYM_E_LIMIT);
     P.rec32 = (E <= 32 && NP <= 512 && c->n_slots <= 1023) ? 1 : 0;
     P.alpha0_cl = cl[0];
     std::vector<uint64_t> mask((size_t)NP * 2, 0);
@@ -486,6 +493,13 @@ static int build(ongym_env *env, const ongym_config *c) {
     if ((rc = dev_alloc(env, B * c->capacity, &P.svc_a, true))) return rc;
     if ((rc = dev_alloc(env, B * c->capacity, &P.svc_b, true))) return rc;
     if ((rc = dev_alloc(env, B * c->capacity, &P.svc_r, true))) return rc;
+    P.svc_q = nullptr; P.svc_o = nullptr; P.move_log = nullptr; P.move_n = nullptr;
+    if (P.defragmentation) {
+        if ((rc = dev_alloc(env, B * c->capacity, &P.svc_q, true))) return rc;
+        if ((rc = dev_alloc(env, B * c->capacity, &P.svc_o, true))) return rc;
+        if ((rc = dev_alloc(env, B * ONGYM_MOVE_LOG, &P.move_log, true))) return rc;
+        if ((rc = dev_alloc(env, B, &P.move_n, true))) return rc;
+    }
     if ((rc = dev_alloc(env, B, &P.env, false))) return rc;
     std::vector<DevEnv> host(B);
     memset(host.data(), 0, B * sizeof(DevEnv));
@@ -497,7 +511,6 @@ static int build(ongym_env *env, const ongym_config *c) {
         if (!(load > 0) || !(d.launch_power > 0)) return fail_arg(env, "per-replica load / launch power must be positive");
         d.mean_iat = 1 / (load / c->mean_holding_time);   // set_load, envs/qrmsa.pyx:1124-1132
         d.mean_iat_f = (float)d.mean_iat;
-        d.min_rel = INFINITY;
     }
     HIP_TRY(env, hipMemcpy(P.env, host.data(), B * sizeof(DevEnv), hipMemcpyHostToDevice));
     // the bitmaps start "all free" so that queries before the first reset see an empty network
@@ -512,7 +525,7 @@ static int build(ongym_env *env, const ongym_config *c) {
         for (size_t i = 0; i < all.size(); i++) all[i] = row[i % P.row_words];
         HIP_TRY(env, hipMemcpy(P.occ, all.data(), all.size() * 8, hipMemcpyHostToDevice));
     }
-    env->lds = lds_bytes(E, P.row_words, c->capacity, P.uniform_alpha, P.measure_disruptions);
+    env->lds = lds_bytes(P);
     if (env->lds > 64 * 1024) {
         if (env->lds > 160 * 1024) return fail_arg(env, "state does not fit the 160 KiB LDS: lower capacity", ONGYM_E_LIMIT);
 #define ONGYM_SET_LDS(K) HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->lds))
@@ -520,6 +533,10 @@ static int build(ongym_env *env, const ongym_config *c) {
         ONGYM_SET_LDS((k_run<false, true, 4, 0>)); ONGYM_SET_LDS((k_run<false, false, 4, 0>));
         ONGYM_SET_LDS((k_run<true, true, 4, 1>)); ONGYM_SET_LDS((k_run<true, false, 4, 1>));
         ONGYM_SET_LDS((k_run<false, true, 4, 1>)); ONGYM_SET_LDS((k_run<false, false, 4, 1>));
+        if (P.defragmentation) {
+            ONGYM_SET_LDS((k_run<true, true, 4, 0, true>)); ONGYM_SET_LDS((k_run<true, false, 4, 0, true>));
+            ONGYM_SET_LDS((k_run<true, true, 4, 1, true>)); ONGYM_SET_LDS((k_run<true, false, 4, 1, true>));
+        }
         ONGYM_SET_LDS((k_query<true, true>)); ONGYM_SET_LDS((k_query<true, false>));
         ONGYM_SET_LDS((k_query<false, true>)); ONGYM_SET_LDS((k_query<false, false>));
         ONGYM_SET_LDS((k_query_gsnr_many<true, true>)); ONGYM_SET_LDS((k_query_gsnr_many<true, false>));
@@ -553,6 +570,7 @@ int32_t ongym_sizeof(int32_t what) {
         case 2: return (int32_t)sizeof(ongym_step_rec);
         case 3: return (int32_t)sizeof(ongym_service);
         case 4: return (int32_t)sizeof(ongym_stats);
+        case 5: return (int32_t)sizeof(ongym_move);
         default: return -1;
     }
 }
@@ -695,6 +713,30 @@ static int launch_run(ongym_env *env, int mode, int policy, int nsteps, const in
             HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_run<true, false, 4, ONGYM_POLICY_HIGHEST_SNR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)field_lds(env)));
         }
     }
+#define ONGYM_LAUNCH_DEFRAG(R, POL, LDS)                                                                           \
+    hipLaunchKernelGGL((k_run<true, R, 4, POL, true>), grid, block, LDS, env->stream, env->d_P, mode, nsteps,      \
+                       d_actions, d_act_out, d_flag_out, d_out)
+    if (env->P.defragmentation) {   // defragmentation (needs uniform attenuation, checked at create): own instantiations
+        if (policy == ONGYM_POLICY_HIGHEST_SNR) {
+            if (field_lds(env) > 64 * 1024) {
+                HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_run<true, true, 4, ONGYM_POLICY_HIGHEST_SNR, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)field_lds(env)));
+                HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_run<true, false, 4, ONGYM_POLICY_HIGHEST_SNR, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)field_lds(env)));
+            }
+            if (env->P.rec32) ONGYM_LAUNCH_DEFRAG(true, ONGYM_POLICY_HIGHEST_SNR, field_lds(env));
+            else ONGYM_LAUNCH_DEFRAG(false, ONGYM_POLICY_HIGHEST_SNR, field_lds(env));
+        } else if (policy == ONGYM_POLICY_LOAD_BALANCING) {
+            if (env->P.rec32) ONGYM_LAUNCH_DEFRAG(true, ONGYM_POLICY_LOAD_BALANCING, env->lds);
+            else ONGYM_LAUNCH_DEFRAG(false, ONGYM_POLICY_LOAD_BALANCING, env->lds);
+        } else {
+            if (env->P.rec32) ONGYM_LAUNCH_DEFRAG(true, ONGYM_POLICY_FIRST_FIT, env->lds);
+            else ONGYM_LAUNCH_DEFRAG(false, ONGYM_POLICY_FIRST_FIT, env->lds);
+        }
+        HIP_TRY(env, hipGetLastError());
+        HIP_TRY(env, hipEventRecord(env->ev1, env->stream));
+        env->timed = true;
+        return 0;
+    }
+#undef ONGYM_LAUNCH_DEFRAG
 #define ONGYM_LAUNCH_RUN(UA, R)                                                                                    \
     do {                                                                                                           \
         if (policy == ONGYM_POLICY_HIGHEST_SNR)                                                                    \
@@ -910,6 +952,23 @@ int ongym_query_path_free(ongym_env *env, int32_t replica, int32_t path_id, int3
     if (rc) return rc;
     HIP_TRY(env, hipMemcpyAsync(out, env->d_scratch_i, 4, hipMemcpyDeviceToHost, env->stream));
     HIP_TRY(env, hipStreamSynchronize(env->stream));
+    return ONGYM_OK;
+}
+
+int ongym_query_moves(ongym_env *env, int32_t replica, ongym_move *out, int32_t *count) {
+    if (!env || !out || !count) return ONGYM_E_ARG;
+    if (replica < 0 || replica >= env->P.batch) return fail_arg(env, "replica out of range");
+    *count = 0;
+    if (!env->P.defragmentation) return ONGYM_OK;
+    HIP_TRY(env, hipSetDevice(env->cfg.device));
+    HIP_TRY(env, hipStreamSynchronize(env->stream));
+    int32_t n = 0;
+    HIP_TRY(env, hipMemcpy(&n, env->P.move_n + replica, sizeof(n), hipMemcpyDeviceToHost));
+    const int32_t kept = n < ONGYM_MOVE_LOG ? n : ONGYM_MOVE_LOG;
+    if (kept > 0)
+        HIP_TRY(env, hipMemcpy(out, env->P.move_log + (size_t)replica * ONGYM_MOVE_LOG, (size_t)kept * sizeof(ongym_move),
+                               hipMemcpyDeviceToHost));
+    *count = n;
     return ONGYM_OK;
 }
 

@@ -33,6 +33,7 @@ class OngymConfig(C.Structure):
         ("batch", C.c_int32), ("capacity", C.c_int32), ("episode_length", C.c_int32), ("auto_reset", C.c_int32),
         ("bit_rate_mode", C.c_int32), ("n_bit_rates", C.c_int32), ("bit_rate_lo", C.c_int32),
         ("bit_rate_hi", C.c_int32), ("device", C.c_int32), ("io_device", C.c_int32), ("measure_disruptions", C.c_int32),
+        ("defragmentation", C.c_int32), ("n_defrag_services", C.c_int32),
         ("frequency_start", C.c_double), ("slot_bandwidth", C.c_double), ("channel_width", C.c_double),
         ("launch_power_w", C.c_double), ("margin", C.c_double), ("load", C.c_double),
         ("mean_holding_time", C.c_double),
@@ -52,7 +53,10 @@ STEP_DTYPE = np.dtype([("action", "<i4"), ("route", "<i2"), ("modulation", "<i2"
                        ("flags", "u1"), ("active", "<i4"), ("osnr", "<f8"), ("ase", "<f8"), ("nli", "<f8"),
                        ("reward", "<f8")], align=True)
 SERVICE_DTYPE = np.dtype([("path_id", "<i4"), ("slot", "<i2"), ("nslots", "<i2"), ("modulation", "<i2"),
-                          ("reserved", "<i2"), ("release_time", "<f4")], align=True)
+                          ("reserved", "<i2"), ("release_time", "<f4"), ("service_id", "<i4"), ("pad_", "<i4"),
+                          ("osnr", "<f8")], align=True)
+MOVE_LOG = 64
+MOVE_DTYPE = np.dtype([("service_id", "<i4"), ("slot", "<i4"), ("osnr", "<f8"), ("ase", "<f8"), ("nli", "<f8")], align=True)
 STATS_DTYPE = np.dtype([
     ("services_processed", "<i8"), ("services_accepted", "<i8"),
     ("episode_services_processed", "<i8"), ("episode_services_accepted", "<i8"),
@@ -60,13 +64,17 @@ STATS_DTYPE = np.dtype([
     ("episode_bit_rate_requested", "<f8"), ("episode_bit_rate_provisioned", "<f8"),
     ("rejected", "<i8"), ("episode_modulation_hist", "<i8", (8,)), ("episode_osnr_sum", "<f8"),
     ("episodes_completed", "<i8"), ("disrupted_services", "<i8"), ("episode_disrupted_services", "<i8"),
+    ("episode_defrag_cycles", "<i8"), ("episode_service_reallocations", "<i8"),
+    ("step_defrag_cycles", "<i8"), ("step_service_reallocations", "<i8"),
+    ("total_steps", "<i8"), ("total_accepted", "<i8"), ("total_gn_evals", "<i8"),
+    ("total_interferer_terms", "<i8"), ("total_paths_tried", "<i8"), ("total_path_hops", "<i8"),
+    ("total_gn_shortcuts", "<i8"), ("total_active_sum", "<i8"), ("current_time", "<f8"), ("active", "<i4"), ("flags", "<i4"),
+    # terminal-step snapshot (kept last, see include/ongym.h)
     ("last_episode_processed", "<i8"), ("last_episode_accepted", "<i8"), ("last_rejected", "<i8"),
     ("last_service_blocking_rate", "<f8"), ("last_episode_service_blocking_rate", "<f8"),
     ("last_bit_rate_blocking_rate", "<f8"), ("last_episode_bit_rate_blocking_rate", "<f8"),
     ("last_modulation_hist", "<i8", (8,)), ("last_mean_gsnr", "<f8"), ("last_episode_disrupted", "<i8"),
-    ("total_steps", "<i8"), ("total_accepted", "<i8"), ("total_gn_evals", "<i8"),
-    ("total_interferer_terms", "<i8"), ("total_paths_tried", "<i8"), ("total_path_hops", "<i8"),
-    ("total_gn_shortcuts", "<i8"), ("total_active_sum", "<i8"), ("current_time", "<f8"), ("active", "<i4"), ("flags", "<i4")], align=True)
+    ("last_episode_defrag_cycles", "<i8"), ("last_episode_service_reallocations", "<i8")], align=True)
 
 
 class ConfigHolder:
@@ -82,6 +90,7 @@ class ConfigHolder:
                  launch_power_dbm: float = 0.0, frequency_start: float = 3e8 / 1565e-9,
                  frequency_slot_bandwidth: float = 12.5e9, margin: float = 0.0, channel_width: float = 12.5,
                  device: int = 0, io_device: bool = False, measure_disruptions: bool = False,
+                 defragmentation: bool = False, n_defrag_services: int = 0,
                  replica_launch_power_dbm: Optional[Sequence[float]] = None,
                  replica_load: Optional[Sequence[float]] = None,
                  replica_margin: Optional[Sequence[float]] = None):
@@ -122,6 +131,7 @@ class ConfigHolder:
         c.bit_rate_lo, c.bit_rate_hi = int(bit_rate_lower_bound), int(bit_rate_higher_bound)  # qrmsa.pyx:250-254
         c.device, c.io_device = int(device), int(bool(io_device))
         c.measure_disruptions = int(bool(measure_disruptions))
+        c.defragmentation, c.n_defrag_services = int(bool(defragmentation)), int(n_defrag_services)
         c.frequency_start, c.slot_bandwidth = float(frequency_start), float(frequency_slot_bandwidth)
         c.channel_width = float(channel_width)
         c.launch_power_w = 10 ** ((float(launch_power_dbm) - 30) / 10)  # qrmsa.pyx:288
@@ -178,6 +188,7 @@ def _declare(lib):
     lib.ongym_query_available.argtypes = [vp, C.c_int32, C.c_int32, vp]
     lib.ongym_query_gsnr.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]
     lib.ongym_query_gsnr_many.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
+    lib.ongym_query_moves.argtypes = [vp, C.c_int32, vp, vp]
     lib.ongym_query_grid.argtypes = [vp, C.c_int32, vp]
     lib.ongym_query_candidates.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp]
     lib.ongym_query_path_free.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]
@@ -192,7 +203,7 @@ def _declare(lib):
     lib.ongym_abi_version.argtypes = []
     lib.ongym_sizeof.argtypes = [C.c_int32]
     for name in ("ongym_create", "ongym_seed", "ongym_set_requests", "ongym_reset", "ongym_step_policy",
-                 "ongym_step_actions", "ongym_policy_actions", "ongym_observe", "ongym_query_available", "ongym_query_gsnr", "ongym_query_gsnr_many",
+                 "ongym_step_actions", "ongym_policy_actions", "ongym_observe", "ongym_query_available", "ongym_query_gsnr", "ongym_query_gsnr_many", "ongym_query_moves",
                  "ongym_query_grid", "ongym_query_services", "ongym_query_request", "ongym_stats_get", "ongym_sync",
                  "ongym_abi_version", "ongym_sizeof", "ongym_query_candidates", "ongym_query_path_free", "ongym_observe"):
         getattr(lib, name).restype = C.c_int32
@@ -200,7 +211,7 @@ def _declare(lib):
 
 EXPORTED_SYMBOLS = (
     "ongym_create", "ongym_destroy", "ongym_seed", "ongym_set_requests", "ongym_reset", "ongym_step_policy",
-    "ongym_step_actions", "ongym_policy_actions", "ongym_observe", "ongym_query_available", "ongym_query_gsnr", "ongym_query_gsnr_many", "ongym_query_grid",
+    "ongym_step_actions", "ongym_policy_actions", "ongym_observe", "ongym_query_available", "ongym_query_gsnr", "ongym_query_gsnr_many", "ongym_query_moves", "ongym_query_grid",
     "ongym_query_services", "ongym_query_request", "ongym_query_candidates", "ongym_query_path_free",
     "ongym_stats_get", "ongym_sync", "ongym_last_kernel_ms",
     "ongym_last_error", "ongym_abi_version", "ongym_sizeof")
@@ -221,7 +232,7 @@ def load_library(path: Optional[str] = None):
     if lib.ongym_abi_version() != ABI_VERSION:
         raise RuntimeError("libongym_hip.so ABI version mismatch")
     sizes = (C.sizeof(OngymConfig), REQUEST_DTYPE.itemsize, STEP_DTYPE.itemsize, SERVICE_DTYPE.itemsize,
-             STATS_DTYPE.itemsize)
+             STATS_DTYPE.itemsize, MOVE_DTYPE.itemsize)
     for what, expect in enumerate(sizes):
         got = lib.ongym_sizeof(what)
         if got != expect:

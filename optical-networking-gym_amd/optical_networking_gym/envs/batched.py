@@ -38,7 +38,7 @@ class BatchedQRMSAEnv:
         mtc = kwargs.pop("modulations_to_consider", 6)
         modulations = list(modulations)[:min(mtc, len(modulations))] if mtc < len(modulations) else list(modulations)
         for dead in ("seed", "allow_rejection", "reset", "file_name", "blocks_to_consider", "gen_observation",
-                     "defragmentation", "n_defrag_services", "bands", "bandwidth", "k_paths"):
+                     "bands", "bandwidth", "k_paths"):
             kwargs.pop(dead, None)
         self.holder = nat.ConfigHolder(tables, modulations=modulations, batch=batch_size, capacity=capacity,
                                        auto_reset=auto_reset, device=device, io_device=io_device, **kwargs)
@@ -149,6 +149,13 @@ class BatchedQRMSAEnv:
         self._check(self.lib.ongym_query_gsnr_many(self._h, replica, len(cands), cands.ctypes.data, out.ctypes.data),
                     "ongym_query_gsnr_many")
         return out
+
+    def moves(self, replica: int):
+        """Reallocations defragment() made during the replica's last step: (records, total count)."""
+        out = np.zeros(nat.MOVE_LOG, nat.MOVE_DTYPE)
+        n = C.c_int32(0)
+        self._check(self.lib.ongym_query_moves(self._h, replica, out.ctypes.data, C.byref(n)), "ongym_query_moves")
+        return out[:min(n.value, nat.MOVE_LOG)], n.value
 
     def candidates(self, row: np.ndarray, nslots: int) -> list:
         """`_get_candidates(row, nslots, len(row))` evaluated on device."""

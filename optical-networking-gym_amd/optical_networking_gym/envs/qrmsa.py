@@ -96,8 +96,7 @@ class QRMSAEnv:
         if gen_observation and (bit_rate_selection != "discrete" or modulations_to_consider < len(topology.graph.get("modulations", []))):
             raise NotImplementedError("gen_observation=True needs discrete bit rates and modulations_to_consider == "
                                       "len(modulations) (the reference's observation() reads max(bit_rates), qrmsa.pyx:679)")
-        if defragmentation:
-            raise NotImplementedError("defragmentation is not built yet")
+        self.defragmentation, self.n_defrag_services = bool(defragmentation), int(n_defrag_services)
         if bands and gen_observation:
             raise NotImplementedError("bands together with gen_observation=True is not built yet")
         self.measure_disruptions = bool(measure_disruptions)
@@ -147,7 +146,8 @@ class QRMSAEnv:
             node_request_probabilities=node_request_probabilities, bit_rate_lower_bound=bit_rate_lower_bound,
             bit_rate_higher_bound=bit_rate_higher_bound, launch_power_dbm=launch_power_dbm,
             frequency_start=frequency_start, frequency_slot_bandwidth=frequency_slot_bandwidth, margin=margin,
-            channel_width=self._slot_width, measure_disruptions=measure_disruptions)
+            channel_width=self._slot_width, measure_disruptions=measure_disruptions,
+            defragmentation=defragmentation, n_defrag_services=n_defrag_services)
         if requests is not None:
             self._dev.set_requests(requests)           # trace replay (parity tests)
         else:
@@ -197,7 +197,14 @@ class QRMSAEnv:
             path = self._paths_by_id[int(rec["path_id"])]
             mod = self.modulations[int(rec["modulation"])]
             n, s = int(rec["nslots"]), int(rec["slot"])
-            svc = Service(service_id=-1, source=path.node_list[0], source_id=self._nodes.index(path.node_list[0]),
+            if self.defragmentation:   # defragment() moves services and rewrites their OSNR (qrmsa.pyx:1590-1632)
+                listed = self._accepted_by_id.get(int(rec["service_id"]))
+                if listed is not None and listed.initial_slot != s:
+                    listed.initial_slot = s
+                    listed.center_frequency = (self.frequency_start + self.frequency_slot_bandwidth * s
+                                               + self.frequency_slot_bandwidth * (n / 2.0))
+                    listed.OSNR = float(rec["osnr"])
+            svc = Service(service_id=int(rec["service_id"]), source=path.node_list[0], source_id=self._nodes.index(path.node_list[0]),
                           destination=path.node_list[-1], path=path, initial_slot=s, number_slots=n,
                           center_frequency=self.frequency_start + self.frequency_slot_bandwidth * s
                           + self.frequency_slot_bandwidth * (n / 2.0),
@@ -222,6 +229,7 @@ class QRMSAEnv:
             raise NotImplementedError("only_episode_counters reset is not built yet")
         self._dev.reset()
         self.topology.graph["services"] = []
+        self._accepted_by_id = {}
         self.max_modulation_idx = len(self.modulations) - 1
         self._pull_request()
         self._refresh_views()
@@ -262,6 +270,20 @@ class QRMSAEnv:
             cur.path, cur.initial_slot, cur.number_slots = None, -1, 0
             cur.OSNR = cur.ASE = cur.NLI = 0.0
         self.topology.graph["services"].append(cur)
+        if self.defragmentation:
+            if cur.accepted:
+                self._accepted_by_id[cur.service_id] = cur
+            # defragment() ran inside this step's _next_service: replay its moves onto the Service objects (a moved
+            # service may already have departed again, so the running-services view alone would miss it)
+            moves, total = self._dev.moves(0)
+            for mv in moves:
+                listed = self._accepted_by_id.get(int(mv["service_id"]))
+                if listed is not None:
+                    listed.initial_slot = int(mv["slot"])
+                    listed.center_frequency = (self.frequency_start + self.frequency_slot_bandwidth * listed.initial_slot
+                                               + self.frequency_slot_bandwidth * (listed.number_slots / 2.0))
+                    listed.launch_power = self.launch_power
+                    listed.OSNR, listed.ASE, listed.NLI = float(mv["osnr"]), float(mv["ase"]), float(mv["nli"])
         self._pull_request()
         self._refresh_views()
         st = self._last_stats
@@ -296,7 +318,8 @@ class QRMSAEnv:
             "episode_disrupted_services": float(int(st["episode_disrupted_services"]) // ea) if (st["episode_disrupted_services"] > 0 and ea > 0) else 0.0,
             "osnr": float(rec["osnr"]), "osnr_req": float(osnr_req),
             "chosen_path_index": int(rec["route"]), "chosen_slot": int(rec["slot"]),
-            "episode_defrag_cicles": 0, "episode_service_realocations": 0,
+            "episode_defrag_cicles": int(st["step_defrag_cycles"]),
+            "episode_service_realocations": int(st["step_service_reallocations"]),
         }
         if terminated:   # the device snapshots the exact fp64 rates at the terminal step
             info["service_blocking_rate"] = float(st["last_service_blocking_rate"])

@@ -56,6 +56,7 @@ typedef struct orc_env {
     int32_t *run;           /* [E][cap] per-link running_services, insertion order (envs/qrmsa.pyx:1304-1305) */
     int32_t *run_cnt;       /* [E] */
     int32_t n_running;      /* len(topology.graph["running_services"]) */
+    int32_t *glist;         /* topology.graph["running_services"] itself, insertion order (envs/qrmsa.pyx:1306, 1350) */
     orc_event *heap; int32_t n_heap;
     orc_service cur;        /* current_service */
     int new_service;        /* _new_service */
@@ -68,6 +69,8 @@ typedef struct orc_env {
     double ep_osnr_sum; int64_t ep_services_listed; /* for mean_gsnr: topology.graph["services"] */
     int64_t episodes_completed;
     int64_t disrupted_services, ep_disrupted_services;   /* envs/qrmsa.pyx:315-316, 468-469 */
+    int64_t ep_defrag_cycles, ep_reallocations;          /* envs/qrmsa.pyx:412-413, 438-439, 1546, 1635 */
+    int64_t step_defrag_cycles, step_reallocations;      /* ... as the last step's info dict saw them (:1008-1009) */
     ongym_stats last; /* snapshot at last terminal step */
     int64_t total_steps, total_accepted, total_gn, total_terms, total_paths, total_hops, total_active_sum;
     /* request source */
@@ -107,6 +110,7 @@ orc_env *orc_create(const ongym_config *c, int replica) {
     e->pool_free = (int32_t *)malloc(sizeof(int32_t) * e->pool_cap);
     e->run = (int32_t *)malloc(sizeof(int32_t) * E * e->pool_cap);
     e->run_cnt = (int32_t *)calloc(E, sizeof(int32_t));
+    e->glist = (int32_t *)malloc(sizeof(int32_t) * e->pool_cap);
     e->heap = (orc_event *)malloc(sizeof(orc_event) * e->pool_cap);
     e->max_mod_idx = M - 1;
     e->current_time = 0.0;
@@ -120,7 +124,7 @@ void orc_destroy(orc_env *e) {
     free(e->pair_paths); free(e->path_hops); free(e->path_links); free(e->link_nspans); free(e->link_span_km);
     free(e->link_alpha); free(e->link_nf); free(e->mod_se); free(e->mod_thr); free(e->bit_rates);
     free(e->bit_rate_cum); free(e->node_cum); free(e->grid); free(e->pool); free(e->pool_free); free(e->run);
-    free(e->run_cnt); free(e->heap); free(e->scratch_intf); free(e->scratch_avail); free(e);
+    free(e->run_cnt); free(e->glist); free(e->heap); free(e->scratch_intf); free(e->scratch_avail); free(e);
 }
 
 void orc_seed(orc_env *e, uint64_t seed, uint64_t replica) {
@@ -172,6 +176,11 @@ static void release_path(orc_env *e, int32_t si) {
         for (; k + 1 < n; k++) lst[k] = lst[k + 1];
         e->run_cnt[l] = n - 1;
     }
+    {   /* topology.graph["running_services"].remove(service), :1350 */
+        int n = e->n_running, k = 0;
+        while (k < n && e->glist[k] != si) k++;
+        for (; k + 1 < n; k++) e->glist[k] = e->glist[k + 1];
+    }
     e->n_running--;
     e->pool_free[e->n_pool_free++] = si;
 }
@@ -181,6 +190,8 @@ int orc_number_slots(const orc_env *e, float bit_rate, int mod) {
     double required = (double)bit_rate / ((double)e->mod_se[mod] * e->cfg.channel_width);
     return (int)ceil(required);
 }
+
+static void defragment(orc_env *e, int num_services);
 
 /* ---- _next_service (envs/qrmsa.pyx:1067-1122) ---------------------------------------------------------------- */
 static int next_service(orc_env *e) {
@@ -210,6 +221,9 @@ static int next_service(orc_env *e) {
         float time = (float)ev.key;                                /* `cdef float time` */
         if (time <= e->current_time) {
             release_path(e, ev.svc);
+            if (e->cfg.defragmentation &&                          /* :1117-1119 */
+                (e->cfg.n_defrag_services == 0 || e->ep_processed % e->cfg.n_defrag_services == 0))
+                defragment(e, e->cfg.n_defrag_services);
         } else {
             ev.key = time; heap_push(e, ev);
             break;
@@ -228,6 +242,7 @@ int orc_reset(orc_env *e) {
     e->bit_rate_requested = 0.0; e->bit_rate_provisioned = 0.0;   /* :466-467 */
     e->ep_osnr_sum = 0.0; e->ep_services_listed = 0;              /* topology.graph["services"] = [] */
     e->disrupted_services = 0; e->ep_disrupted_services = 0;      /* :432, 468-469 */
+    e->ep_defrag_cycles = 0; e->ep_reallocations = 0;             /* :438-439 */
     e->n_running = 0; memset(e->run_cnt, 0, sizeof(int32_t) * E);
     e->n_pool_free = 0;
     for (int i = e->pool_cap - 1; i >= 0; i--) e->pool_free[e->n_pool_free++] = i;
@@ -362,6 +377,65 @@ static void gn_running(orc_env *e, int32_t si, double out[3]) {
         }
     }
     gn_core(e, y->path_id, y->center_frequency, y->bandwidth, y->launch_power, y->id, lists, counts, out, 0);
+}
+
+/* ---- defragment (envs/qrmsa.pyx:1545-1639) ------------------------------------------------------------------------
+ * Every running service, in the order of topology.graph["running_services"], is offered the candidate starts of its own
+ * path for its own slot count (its current slots still count as occupied); the lowest start below its present one whose
+ * GSNR — evaluated with the service moved there, itself skipped by service_id — is not below minimum_osnr (NO margin)
+ * wins: old [slot, slot+n+1) freed (clamped at S), new [start, start+n(+1 unless it ends at S)) taken, the service goes to
+ * the END of its links' running lists, Service.OSNR/ASE/NLI are overwritten. */
+static void defragment(orc_env *e, int num_services) {
+    int S = e->cfg.n_slots, H = e->cfg.max_hops;
+    e->ep_defrag_cycles += 1;
+    if (num_services == 0) num_services = 1000000;
+    int moved = 0, n_active = e->n_running;
+    int32_t *active = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_active + 1));
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (size_t)(S + 1));
+    memcpy(active, e->glist, sizeof(int32_t) * (size_t)n_active);      /* list(...) copy, :1557 */
+    for (int a = 0; a < n_active; a++) {
+        orc_service *s = &e->pool[active[a]];
+        if (moved >= num_services) break;
+        int p = s->path_id, n = s->nslots, old_slot = s->slot;
+        double old_fc = s->center_frequency, old_bw = s->bandwidth;
+        orc_available(e, p, e->scratch_avail);
+        int nc = orc_candidates(e->scratch_avail, S, n, cand, S + 1);
+        for (int q = 0; q < nc; q++) {
+            int start = cand[q];
+            if (start >= s->slot) continue;
+            int end = start + n;
+            if (end < S) end += 1; else if (end > S) continue;
+            s->slot = start;
+            s->center_frequency = center_freq(e, start, n);
+            s->bandwidth = e->cfg.slot_bandwidth * n;
+            s->launch_power = e->launch_power;
+            double o[3];
+            gn_running(e, active[a], o);
+            if (o[0] < e->mod_thr[s->mod]) {
+                s->slot = old_slot; s->center_frequency = old_fc; s->bandwidth = old_bw;
+                continue;
+            }
+            for (int h = 0; h < e->path_hops[p]; h++) {
+                int l = e->path_links[p * H + h];
+                int oe = old_slot + n + 1; if (oe > S) oe = S;
+                for (int j = old_slot; j < oe; j++) e->grid[l * S + j] = 1;
+                int32_t *lst = &e->run[(size_t)l * e->pool_cap]; int cnt = e->run_cnt[l], k = 0;
+                while (k < cnt && lst[k] != active[a]) k++;
+                for (; k + 1 < cnt; k++) lst[k] = lst[k + 1];
+                e->run_cnt[l] = cnt - 1;
+            }
+            for (int h = 0; h < e->path_hops[p]; h++) {
+                int l = e->path_links[p * H + h];
+                for (int j = start; j < end; j++) e->grid[l * S + j] = 0;
+                e->run[(size_t)l * e->pool_cap + e->run_cnt[l]++] = active[a];
+            }
+            e->ep_osnr_sum += o[0] - s->osnr;                      /* the object in topology.graph["services"] is updated */
+            s->osnr = o[0]; s->ase = o[1]; s->nli = o[2];
+            moved += 1; e->ep_reallocations += 1;
+            break;
+        }
+    }
+    free(active); free(cand);
 }
 
 /* GN with explicit per-link interferer lists (for the captured known-answer tests):
@@ -539,7 +613,7 @@ static int provision(orc_env *e, int path_id, int slot, int n) {
         for (int j = slot; j < end; j++) e->grid[l * S + j] = 0;
         e->run[(size_t)l * e->pool_cap + e->run_cnt[l]++] = si;
     }
-    e->n_running++;
+    e->glist[e->n_running++] = si;
     e->services_accepted += 1; e->ep_accepted += 1;
     e->bit_rate_provisioned += e->cur.bit_rate;
     e->ep_bit_rate_provisioned = (double)(int64_t)(e->ep_bit_rate_provisioned + e->cur.bit_rate); /* :1319-1321 */
@@ -564,6 +638,7 @@ static void snapshot_terminal(orc_env *e) {
     memcpy(s->last_modulation_hist, e->ep_mod_hist, sizeof(e->ep_mod_hist));
     s->last_mean_gsnr = e->ep_services_listed ? e->ep_osnr_sum / (double)e->ep_services_listed : 0.0;
     s->last_episode_disrupted = e->ep_disrupted_services;
+    s->last_episode_defrag_cycles = e->ep_defrag_cycles; s->last_episode_service_reallocations = e->ep_reallocations;
 }
 
 /* ---- step (envs/qrmsa.pyx:838-1065), gen_observation=False, measure_disruptions=False, no CSV ------------------ */
@@ -636,11 +711,17 @@ int orc_step(orc_env *e, int action, ongym_step_rec *out) {
     e->new_service = 0;                                            /* :1052 */
     e->total_steps++;
     /* info rates are computed BEFORE _next_service (:996-1050) */
+    e->step_defrag_cycles = e->ep_defrag_cycles; e->step_reallocations = e->ep_reallocations;
     int will_terminate = (e->ep_processed + 1 == e->cfg.episode_length);
     if (will_terminate) snapshot_terminal(e);
     next_service(e);                                               /* :1054 */
     r.terminated = (uint8_t)(e->ep_processed == e->cfg.episode_length); /* :1056 */
-    if (r.terminated) e->episodes_completed++;
+    if (r.terminated) {
+        e->episodes_completed++;
+        /* graph_load.py:181-185 reads Service.OSNR AFTER the loop, i.e. after this step's _next_service: the departures
+         * it processed may have run defragment(), which rewrites the OSNR of the services it moves */
+        e->last.last_mean_gsnr = e->ep_services_listed ? e->ep_osnr_sum / (double)e->ep_services_listed : 0.0;
+    }
     r.active = e->n_running;
     e->total_active_sum += e->n_running;
     if (out) *out = r;
@@ -658,6 +739,8 @@ void orc_stats(const orc_env *e, ongym_stats *s) {
     memcpy(s->episode_modulation_hist, e->ep_mod_hist, sizeof(e->ep_mod_hist));
     s->episode_osnr_sum = e->ep_osnr_sum; s->episodes_completed = e->episodes_completed;
     s->disrupted_services = e->disrupted_services; s->episode_disrupted_services = e->ep_disrupted_services;
+    s->episode_defrag_cycles = e->ep_defrag_cycles; s->episode_service_reallocations = e->ep_reallocations;
+    s->step_defrag_cycles = e->step_defrag_cycles; s->step_service_reallocations = e->step_reallocations;
     s->total_steps = e->total_steps; s->total_accepted = e->total_accepted; s->total_gn_evals = e->total_gn;
     s->total_interferer_terms = e->total_terms; s->total_paths_tried = e->total_paths;
     s->total_path_hops = e->total_hops; s->total_active_sum = e->total_active_sum;
@@ -678,7 +761,9 @@ int orc_services(const orc_env *e, ongym_service *out) {
     for (int i = 0; i < e->n_heap; i++) {
         const orc_service *s = &e->pool[e->heap[i].svc];
         out[n].path_id = s->path_id; out[n].slot = (int16_t)s->slot; out[n].nslots = (int16_t)s->nslots;
-        out[n].modulation = (int16_t)s->mod; out[n].reserved = 0; out[n].release_time = (float)e->heap[i].key; n++;
+        out[n].modulation = (int16_t)s->mod; out[n].reserved = 0; out[n].release_time = (float)e->heap[i].key;
+        out[n].service_id = e->cfg.defragmentation ? s->id : -1; out[n].pad_ = 0;   /* like the device: kept only then */
+        out[n].osnr = e->cfg.defragmentation ? s->osnr : 0.0; n++;
     }
     return n;
 }

@@ -170,7 +170,8 @@ def link_state(env, link):
 
 def run_trajectory(tag, topo_name, seed, load, S, episodes, episode_length=1000, bit_rates=(10, 40, 100, 400),
                    launch_power_dbm=0.0, margin=0.0, bit_rate_selection="discrete", scripted=False,
-                   gn_every=41, snap_steps=(100, 400, 700, 998), k=5, policy="first_fit", measure_disruptions=False):
+                   gn_every=41, snap_steps=(100, 400, 700, 998), k=5, policy="first_fit", measure_disruptions=False,
+                   defragmentation=False, n_defrag_services=0):
     topo = load_topology(topo_name, k)
     nodes = list(topo.nodes())
     gn_samples = []
@@ -194,8 +195,8 @@ def run_trajectory(tag, topo_name, seed, load, S, episodes, episode_length=1000,
             num_spectrum_resources=S, launch_power_dbm=launch_power_dbm, bandwidth=S * 12.5e9,
             frequency_start=3e8 / 1565e-9, frequency_slot_bandwidth=12.5e9, bit_rate_selection=bit_rate_selection,
             bit_rates=bit_rates, bit_rate_lower_bound=25, bit_rate_higher_bound=100, margin=margin, file_name="",
-            measure_disruptions=measure_disruptions, k_paths=k, modulations_to_consider=6, defragmentation=False,
-            n_defrag_services=0, gen_observation=False)
+            measure_disruptions=measure_disruptions, k_paths=k, modulations_to_consider=6,
+            defragmentation=defragmentation, n_defrag_services=n_defrag_services, gen_observation=False)
     finally:
         random.Random = _OrigRandom
     policy_fn = {"first_fit": H.heuristic_shortest_available_path_first_fit_best_modulation,
@@ -242,7 +243,7 @@ def run_trajectory(tag, topo_name, seed, load, S, episodes, episode_length=1000,
                 steps.append(dict(action=int(action), accepted=0, route=-1, mod=-1, slot=-1, n=0, osnr=0.0, ase=0.0,
                                   nli=0.0, reward=float(reward), term=0, bres=int(bool(bres)), bosnr=int(bool(bosnr)),
                                   active=len(env.env.topology.graph["running_services"]), retry=1,
-                                  ep_acc=-1, disr=0.0, ep_disr=0.0))
+                                  ep_acc=-1, disr=0.0, ep_disr=0.0, dcyc=0, drea=0))
                 gstep += 1
                 continue
             svc = env.env.topology.graph["services"][-1]
@@ -253,11 +254,16 @@ def run_trajectory(tag, topo_name, seed, load, S, episodes, episode_length=1000,
                     svc.current_modulation.spectral_efficiency)
             steps.append(dict(action=int(action), accepted=int(svc.accepted), route=int(info["chosen_path_index"]),
                               mod=mod_idx, slot=int(info["chosen_slot"]), n=int(svc.number_slots),
-                              osnr=float(svc.OSNR), ase=float(svc.ASE), nli=float(svc.NLI), reward=float(reward),
+                              # with defragmentation the step's own _next_service may already have moved the service and
+                              # rewritten OSNR/ASE/NLI (qrmsa.pyx:1630-1632): info["osnr"] is the provisioning-time value
+                              osnr=float(info["osnr"]) if defragmentation and svc.accepted else float(svc.OSNR),
+                              ase=float("nan") if defragmentation else float(svc.ASE),
+                              nli=float("nan") if defragmentation else float(svc.NLI), reward=float(reward),
                               term=int(done), bres=int(bool(bres)), bosnr=int(bool(bosnr)),
                               active=len(env.env.topology.graph["running_services"]), retry=0,
                               ep_acc=int(info["episode_services_accepted"]),
-                              disr=float(info["disrupted_services"]), ep_disr=float(info["episode_disrupted_services"])))
+                              disr=float(info["disrupted_services"]), ep_disr=float(info["episode_disrupted_services"]),
+                              dcyc=int(info["episode_defrag_cicles"]), drea=int(info["episode_service_realocations"])))
             reqs.append(request_tuple(env)); kinds.append(1)
             if ep == 0 and estep in snap_steps:
                 grid = np.asarray(env.env.topology.graph["available_slots"], dtype=np.uint8)
@@ -284,6 +290,9 @@ def run_trajectory(tag, topo_name, seed, load, S, episodes, episode_length=1000,
                     ("bosnr", np.uint8), ("active", np.int32), ("retry", np.uint8), ("ep_acc", np.int32),
                     ("disr", np.float64), ("ep_disr", np.float64)):
         out["st_" + key] = np.array([s[key] for s in steps], dtype=dt)
+    if defragmentation:
+        out["st_dcyc"] = np.array([s["dcyc"] for s in steps], np.int32)
+        out["st_drea"] = np.array([s["drea"] for s in steps], np.int32)
     if snaps:
         out["snap_step"] = np.array(snap_at, dtype=np.int32)
         out["snap_grid"] = np.stack(snaps)
@@ -305,7 +314,8 @@ def run_trajectory(tag, topo_name, seed, load, S, episodes, episode_length=1000,
                 frequency_start=3e8 / 1565e-9, slot_bw=12.5e9, mean_holding=10800.0,
                 terminal_infos=terminal_infos, n_steps=len(steps), n_requests=len(reqs),
                 launch_power_w=float(env.env.launch_power), reject_action=int(reject), initial_resets=3,
-                policy=policy, measure_disruptions=measure_disruptions)
+                policy=policy, measure_disruptions=measure_disruptions, defragmentation=defragmentation,
+                n_defrag_services=n_defrag_services)
     np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **out)
     json.dump(meta, open(os.path.join(HERE, f"{tag}.json"), "w"), indent=1)
     acc = out["st_accepted"].mean()
@@ -575,6 +585,12 @@ TRAJ = {
     # measure_disruptions=True (qrmsa.pyx:937-952): NLI-dominated regime so that new services push old ones under threshold
     "traj_nsfnet320_disr": dict(topo_name="nsfnet", seed=61, load=500, S=320, episodes=2, launch_power_dbm=3.0,
                                 measure_disruptions=True),
+    # defragmentation=True (qrmsa.pyx:1117-1119, 1545-1639): after every departure (n = 0) / every 4th request, <= 4 moves
+    "traj_nsfnet320_defrag": dict(topo_name="nsfnet", seed=71, load=250, S=320, episodes=2, episode_length=500,
+                                  defragmentation=True, n_defrag_services=0, snap_steps=(100, 300, 450), launch_power_dbm=1.0),
+    "traj_nsfnet320_defrag4": dict(topo_name="nsfnet", seed=72, load=400, S=320, episodes=2, episode_length=600,
+                                   defragmentation=True, n_defrag_services=4, snap_steps=(100, 300, 550),
+                                   bit_rates=(10, 40, 100, 400, 1000)),
     "traj_nobeleu320_lb": dict(topo_name="nobel-eu", seed=18, load=700, S=320, episodes=1, policy="load_balancing",
                                launch_power_dbm=1.0),
 }

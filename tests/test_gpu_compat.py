@@ -200,3 +200,24 @@ def test_bands_quirk_and_service_csv(tmp_path):
                         "disrupted_services,active_services")
     assert len(lines) == 2 + 39 and len(lines[2].split(",")) == 13
     assert sim.final_file_name.endswith("_nsfnet_chen_0.0_300.0_7.csv")
+
+
+def test_defragmentation_through_the_wrapper():
+    """defragmentation=True (graph_load.py passes it through env_args): info counters per step, and the episode's mean
+    GSNR over topology.graph["services"], whose moved members carry the OSNR defragment() rewrote."""
+    env, meta, d = jocn_env("traj_nsfnet320_defrag", defragmentation=True, n_defrag_services=0)
+    sim = get_qrmsa_env(env)
+    env.reset()
+    i = 0
+    done = False
+    while not done:
+        action, _, _ = heuristic_shortest_available_path_first_fit_best_modulation(env)
+        assert action == d["st_action"][i]
+        _, _, done, _, info = env.step(action)
+        assert info["episode_defrag_cicles"] == d["st_dcyc"][i], i
+        assert info["episode_service_realocations"] == d["st_drea"][i], i
+        i += 1
+    ti = meta["terminal_infos"][0]
+    services = sim.topology.graph["services"]
+    assert len(services) == ti["n_services"] and d["st_drea"][i - 1] > 20
+    assert sum(s.OSNR for s in services) / len(services) == pytest.approx(ti["mean_gsnr"], rel=1e-9)

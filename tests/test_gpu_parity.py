@@ -401,3 +401,84 @@ def test_measure_disruptions_vs_reference_and_oracle():
         flagged = env.services(r)
         assert int(flagged["reserved"].sum()) <= so["disrupted_services"]      # some disrupted services have departed
     assert st["disrupted_services"].max() > 10 and len(np.unique(st["disrupted_services"])) > 5
+
+
+# ---- defragmentation (qrmsa.pyx:1117-1119, 1545-1639) -----------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["traj_nsfnet320_defrag", "traj_nsfnet320_defrag4"])
+def test_defragmentation_vs_reference(tag):
+    """The reference run with defragmentation=True: decisions, grid snapshots (they move with every reallocation), the
+    per-step info counters and the episode's mean GSNR (which sees the OSNR defragment() rewrites)."""
+    meta, d = load_traj(tag)
+    env = make_env(meta, auto_reset=True, defragmentation=True, n_defrag_services=meta["n_defrag_services"])
+    env.set_requests(traj_requests(d))
+    for _ in range(meta["initial_resets"]):
+        env.reset()
+    snaps = {int(s): i for i, s in enumerate(d["snap_step"])}
+    cuts = sorted(set([s + 1 for s in snaps] + [57, meta["episode_length"] - 1, meta["n_steps"]]))
+    done = 0
+    for cut in cuts:
+        rec = env.step_policy(cut - done)[:, 0]
+        sl = slice(done, cut)
+        for f, g in (("action", "st_action"), ("accepted", "st_accepted"), ("terminated", "st_term"), ("active", "st_active"),
+                     ("route", "st_route"), ("slot", "st_slot"), ("reward", "st_reward")):
+            assert np.array_equal(rec[f], d[g][sl]), (f, done)
+        acc = d["st_accepted"][sl] == 1
+        np.testing.assert_allclose(rec["osnr"][acc], d["st_osnr"][sl][acc], rtol=GSNR_RTOL)
+        done = cut
+        st = env.stats()[0]
+        if not rec["terminated"][-1]:      # (auto-reset zeroes the episode counters right after a terminal step)
+            assert st["step_defrag_cycles"] == d["st_dcyc"][done - 1], done
+            assert st["step_service_reallocations"] == d["st_drea"][done - 1], done
+        if done - 1 in snaps:
+            grid = np.unpackbits(d["snap_grid"][snaps[done - 1]], axis=1, bitorder="little")[:, :meta["S"]]
+            np.testing.assert_array_equal(env.grid(0), grid.astype(np.int32))
+        if done == meta["episode_length"] - 1:
+            ti = meta["terminal_infos"][0]
+            assert st["last_mean_gsnr"] == pytest.approx(ti["mean_gsnr"], rel=1e-9)
+            assert st["last_episode_defrag_cycles"] == ti["episode_defrag_cicles"]
+            assert st["last_episode_service_reallocations"] == ti["episode_service_realocations"]
+    st = env.stats()[0]
+    ti = meta["terminal_infos"][-1]
+    assert st["episodes_completed"] == meta["episodes"]
+    assert st["last_mean_gsnr"] == pytest.approx(ti["mean_gsnr"], rel=1e-9)
+    assert st["last_episode_service_reallocations"] == ti["episode_service_realocations"] > 20
+
+
+@pytest.mark.parametrize("n_defrag,topo,S,load", [(0, "nsfnet", 320, 260), (6, "cost239", 320, 420), (3, "nobel-eu", 256, 300)])
+def test_defragmentation_random_traffic_vs_oracle(n_defrag, topo, S, load):
+    """device traffic generator + defragmentation against the CPU oracle: records, grids, the running services with
+    their ids and rewritten OSNR, the counters; per-replica launch power; crosses an episode boundary."""
+    B, steps = 12, 620
+    lps = np.linspace(-2.0, 3.0, B)
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=S, batch=B, capacity=1024, episode_length=400,
+              auto_reset=True, load=load, bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400),
+              replica_launch_power_dbm=lps, defragmentation=True, n_defrag_services=n_defrag)
+    holder = nat.ConfigHolder(golden_tables(topo), **kw)
+    env = BatchedQRMSAEnv(tables=golden_tables(topo), modulations=jocn_modulations(), batch_size=B,
+                          num_spectrum_resources=S, capacity=1024, episode_length=400, auto_reset=True, load=load,
+                          bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), replica_launch_power_dbm=lps,
+                          defragmentation=True, n_defrag_services=n_defrag)
+    env.seed(77); env.reset()
+    got = np.concatenate([env.step_policy(211), env.step_policy(steps - 211)])
+    st = env.stats()
+    moved = 0
+    for r in range(B):
+        o = OracleEnv(holder, replica=r)
+        o.seed(77); o.reset()
+        want = o.run_first_fit(steps)
+        assert_records_equal(got[:, r], want, f"replica {r}")
+        so = o.stats()
+        for f in ("episode_defrag_cycles", "episode_service_reallocations", "step_defrag_cycles",
+                  "step_service_reallocations", "last_episode_defrag_cycles", "last_episode_service_reallocations",
+                  "services_accepted", "episodes_completed", "active"):
+            assert st[r][f] == so[f], (r, f, st[r][f], so[f])
+        assert st[r]["last_mean_gsnr"] == pytest.approx(so["last_mean_gsnr"], rel=1e-9)
+        assert st[r]["episode_osnr_sum"] == pytest.approx(so["episode_osnr_sum"], rel=1e-9)
+        np.testing.assert_array_equal(env.grid(r), o.grid())
+        a = np.sort(env.services(r), order="service_id")
+        b = np.sort(o.services(), order="service_id")
+        for f in ("service_id", "path_id", "slot", "nslots", "modulation", "release_time"):
+            assert np.array_equal(a[f], b[f]), (r, f)
+        np.testing.assert_allclose(a["osnr"], b["osnr"], rtol=GSNR_RTOL)
+        moved += int(so["last_episode_service_reallocations"])
+    assert moved > 50
