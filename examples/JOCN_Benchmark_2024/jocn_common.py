@@ -41,10 +41,14 @@ def csv_header(modulations):
 def csv_row(ep, st, n_mods, ep_time):
     # reference graph_load.py:169-186 (info of the terminal step + mean of Service.OSNR)
     row = (f"{ep},{st['last_service_blocking_rate']},{st['last_episode_service_blocking_rate']},"
-           f"{st['last_bit_rate_blocking_rate']},{st['last_episode_bit_rate_blocking_rate']},0,0")
+           f"{st['last_bit_rate_blocking_rate']},{st['last_episode_bit_rate_blocking_rate']},"
+           f"{int(st['last_episode_service_reallocations'])},{int(st['last_episode_defrag_cycles'])}")
     for m in range(n_mods):
         row += f",{int(st['last_modulation_hist'][m])}"
-    return row + f",0,{ep_time:.2f},{st['last_mean_gsnr']}\n"
+    # info["episode_disrupted_services"] divides two C ints in the reference (qrmsa.pyx:1038-1041)
+    acc = int(st["last_episode_accepted"])
+    disrupted = float(int(st["last_episode_disrupted"]) // acc) if acc > 0 and st["last_episode_disrupted"] > 0 else 0.0
+    return row + f",{disrupted},{ep_time:.2f},{st['last_mean_gsnr']}\n"
 
 
 def run_sweep(topology, *, n_episodes, episode_length, replicas_per_point, points, seed, common, monitor_names,
@@ -90,3 +94,43 @@ def run_sweep(topology, *, n_episodes, episode_length, replicas_per_point, point
         f.close()
     env.close()
     return [np.array(b) for b in blocking]
+
+
+def run_sweep_plugin(topology, heuristic, *, n_episodes, episode_length, points, seed, common, monitor_names):
+    """The same sweep for a policy that exists only as a plugin (f(env) -> (action, flag, flag), e.g. heuristic 3 of the
+    reference's graph_load.py): one device-backed QRMSAEnvWrapper per point, episodes in sequence, the reference's loop
+    (graph_load.py:157-186) verbatim.  Orders of magnitude slower than the fused policies."""
+    from optical_networking_gym.wrappers.qrmsa_gym import QRMSAEnvWrapper
+    S = common.get("num_spectrum_resources", 320)
+    blocking = []
+    for i, (pt, name) in enumerate(zip(points, monitor_names)):
+        kw = dict(common)
+        kw.update(pt)
+        kw.pop("capacity", None)
+        env = QRMSAEnvWrapper(topology=topology, seed=seed + i, allow_rejection=True, episode_length=episode_length,
+                              bandwidth=S * 12.5e9, frequency_start=3e8 / 1565e-9, frequency_slot_bandwidth=12.5e9,
+                              k_paths=5, modulations_to_consider=6, gen_observation=False, **kw)
+        env.reset()
+        os.makedirs(os.path.dirname(name) or ".", exist_ok=True)
+        rates = []
+        with open(name, "wt", encoding="UTF-8") as f:
+            f.write(f"# Date: {datetime.now()}\n")
+            f.write(csv_header(env.env.modulations))
+            for ep in range(n_episodes):
+                env.reset()
+                done, t0 = False, time.time()
+                while not done:
+                    action, _, _ = heuristic(env)
+                    _, _, done, _, info = env.step(action)
+                row = (f"{ep},{info['service_blocking_rate']},{info['episode_service_blocking_rate']},"
+                       f"{info['bit_rate_blocking_rate']},{info['episode_bit_rate_blocking_rate']},"
+                       f"{info['episode_service_realocations']},{info['episode_defrag_cicles']}")
+                for mf in env.env.modulations:
+                    row += f",{info.get(f'modulation_{float(mf.spectral_efficiency)}', 0)}"
+                services = env.env.topology.graph["services"]
+                mean_gsnr = sum(s.OSNR for s in services) / len(services) if services else 0.0
+                f.write(row + f",{info.get('episode_disrupted_services', 0)},{time.time() - t0:.2f},{mean_gsnr}\n")
+                rates.append(float(info["episode_service_blocking_rate"]))
+        env.close()
+        blocking.append(np.array(rates))
+    return blocking

@@ -41,3 +41,30 @@ def test_launch_power_sweep_matches_published_curve(tmp_path):
     assert len(lines) == 2 + 256 and len(lines[2].split(",")) == len(lines[1].split(","))
     gsnr = np.array([float(l.split(",")[-1]) for l in lines[2:]])
     assert 14.0 < gsnr.mean() < 20.0
+
+
+def test_drivers_defragmentation_columns_and_plugin_path(tmp_path):
+    """graph_load-style sweep with defragmentation: the CSV's reallocation / defrag-cycle columns come from the device
+    counters; a plugin-only policy runs through the reference's per-env loop and writes the same columns."""
+    import csv
+    sys.path.insert(0, os.path.join(REPO, "examples", "JOCN_Benchmark_2024"))
+    import jocn_common as J
+    from optical_networking_gym.heuristics.heuristics import heuristic_mscl_simplified
+    topology = J.load_topology("nsfnet_chen.txt", 5)
+    common = dict(load=250.0, num_spectrum_resources=320, bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400),
+                  launch_power_dbm=1.0, capacity=1024, defragmentation=True, n_defrag_services=0)
+    names = [str(tmp_path / f"load_{ld}.csv") for ld in (200, 300)]
+    res = J.run_sweep(topology, n_episodes=2, episode_length=300, replicas_per_point=2, seed=5, common=common,
+                      points=[dict(load=200.0), dict(load=300.0)], monitor_names=names, policy=0)
+    assert all(len(r) == 2 for r in res)
+    for name in names:
+        rows = list(csv.reader(l for l in open(name) if not l.startswith("#")))
+        head = [h.strip() for h in rows[0]]
+        assert head[5:7] == ["episode_service_realocations", "episode_defrag_cicles"]
+        assert all(int(r[5]) > 0 and int(r[6]) >= int(r[5]) // 300 for r in rows[1:]) and len(rows) == 3
+    common.pop("defragmentation"); common.pop("n_defrag_services")
+    out = J.run_sweep_plugin(topology, heuristic_mscl_simplified, n_episodes=1, episode_length=120, seed=5, common=common,
+                             points=[dict(load=300.0)], monitor_names=[str(tmp_path / "plugin.csv")])
+    assert len(out) == 1 and 0.0 <= out[0][0] <= 1.0
+    rows = list(csv.reader(l for l in open(tmp_path / "plugin.csv") if not l.startswith("#")))
+    assert len(rows) == 2 and len(rows[1]) == len(rows[0])
