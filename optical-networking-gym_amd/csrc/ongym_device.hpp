@@ -211,6 +211,16 @@ __device__ __forceinline__ const __attribute__((address_space(1))) T *G(const T 
     return (const __attribute__((address_space(1))) T *)p;
 }
 
+// One wavefront per workgroup: the LDS executes a wave's DS instructions in issue order, so a value written by one lane
+// is visible to every lane's later read without draining the memory counters. What is needed is only that the compiler
+// keeps the program order across the point: a wavefront-scope fence (emits no s_waitcnt) around a wave barrier.
+// (__syncthreads() would emit `s_waitcnt vmcnt(0) lgkmcnt(0)` and so also wait for every global load in flight.)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // small wave helpers
 // ---------------------------------------------------------------------------------------------------------------
@@ -375,7 +385,7 @@ __device__ __forceinline__ void mark_links(Ctx &c, int hops, int mylink, int lo,
             c.occ[mylink * P.row_words + w] = free_ ? (v | m) : (v & ~m);
         }
     }
-    __syncthreads();
+    wave_sync();
 }
 
 // same, for a path given as a link mask (links < 32): lane l owns link l.
@@ -389,7 +399,7 @@ __device__ __forceinline__ void mark_mask(Ctx &c, uint32_t mask, int lo, int hi,
             c.occ[c.lane * P.row_words + w] = free_ ? (v | m) : (v & ~m);
         }
     }
-    __syncthreads();
+    wave_sync();
 }
 
 // ---- GN model (core/osnr.pyx:21-142) ----------------------------------------------------------------------------
@@ -412,7 +422,7 @@ __device__ __forceinline__ int gn_build_list(Ctx &c, uint64_t cm0, uint64_t cm1)
         if (ov) c.list[L + __popcll((unsigned long long)(bal & lanes_below(c.lane)))] = (uint16_t)i;
         L += __popcll((unsigned long long)bal);
     }
-    __syncthreads();
+    wave_sync();
     return L;
 }
 
@@ -703,7 +713,7 @@ __device__ __forceinline__ void release_due(Ctx &c, float now) {
             int last = c.active - 1;
             if (c.lane == 0 && idx != last) { c.sa[idx] = c.sa[last]; c.sb[idx] = c.sb[last]; c.sr[idx] = c.sr[last]; }
             c.active = last;
-            __syncthreads();
+            wave_sync();
         }
     }
 }
@@ -766,7 +776,7 @@ __device__ __forceinline__ void draw_next(Ctx &c) {
         at = q.arrival_time; ht = q.holding_time; br = q.bit_rate; src = q.source; dst = q.destination;
     } else {
         if (c.lane == 0) e->st.flags |= ONGYM_F_NO_REQUEST;
-        __syncthreads();
+        wave_sync();
         return;
     }
     // slots needed per modulation: get_number_slots (envs/qrmsa.pyx:1198-1205), lane m -> nreq[m]
@@ -785,7 +795,7 @@ __device__ __forceinline__ void draw_next(Ctx &c) {
         e->st.bit_rate_requested += (double)br;
         e->st.episode_bit_rate_requested += (double)br;
     }
-    __syncthreads();
+    wave_sync();
 }
 
 // fold the running product into DevEnv.st.episode_osnr_sum (lane 0 only)
@@ -813,7 +823,7 @@ __device__ __forceinline__ void reset_env(Ctx &c) {
         e->osnr_flushed = 0.0; c.osnr_prod = 1.0;
         e->have_request = 0;
     }
-    __syncthreads();
+    wave_sync();
     draw_next(c);   // no departures possible: the network is empty
 }
 
@@ -918,7 +928,7 @@ __device__ __forceinline__ int measure_disruptions(Ctx &c, uint64_t nm0, uint64_
             newly++;
         }
     }
-    __syncthreads();
+    wave_sync();
     return newly;
 }
 
@@ -975,7 +985,7 @@ __device__ __forceinline__ void defragment(Ctx &c, int num_services) {
             if (c.lane == (s0 >> 6)) v &= ~(1ull << (s0 & 63));
         }
         if (target < 0) continue;
-        __syncthreads();
+        wave_sync();
         mark_links(c, p.hops, p.mylink, sy, sy + ny + 1, true);
         int end = target + ny; if (end < P.n_slots) end += 1;
         mark_links(c, p.hops, p.mylink, target, end, false);
@@ -997,7 +1007,7 @@ __device__ __forceinline__ void defragment(Ctx &c, int num_services) {
             P.move_n[c.replica] = nlog + 1;
         }
         moved++;
-        __syncthreads();
+        wave_sync();
     }
 }
 
@@ -1037,7 +1047,7 @@ __device__ __forceinline__ void release_due_defrag(Ctx &c, float now) {
             c.sq[idx] = c.sq[lastrec]; c.so[idx] = c.so[lastrec];
         }
         c.active = lastrec;
-        __syncthreads();
+        wave_sync();
         if (P.n_defrag_services == 0 || c.e->st.episode_services_processed % P.n_defrag_services == 0)
             defragment<R32>(c, P.n_defrag_services);
     }
@@ -1133,11 +1143,11 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
     if (outcome == 0) {
         c.active++;
     }
-    __syncthreads();
+    wave_sync();
     if (outcome == 0 && P.measure_disruptions) {
         const int newly = measure_disruptions<R32>(c, ch.m0, R32 ? 0 : G(P.path_mask)[2 * ch.path + 1]);
         if (newly && c.lane == 0) { e->st.disrupted_services += newly; e->st.episode_disrupted_services += newly; }
-        __syncthreads();
+        wave_sync();
     }
     draw_next(c);                                 // first half of _next_service (:1079-1111)
     STAMP(c, 6);
@@ -1154,7 +1164,7 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
         if (rec) { rec->active = c.active; rec->terminated = (uint8_t)terminated; }
     }
     c.active_sum += c.active;
-    if (terminated && P.auto_reset) { __syncthreads(); reset_env(c); }
+    if (terminated && P.auto_reset) { wave_sync(); reset_env(c); }
 }
 
 
@@ -1209,7 +1219,7 @@ __device__ __forceinline__ void build_field(Ctx &c, const PathRef &p, uint64_t f
             if (c.lane < kMaxRowWords) Vw[mi * kMaxRowWords + c.lane] = v;
         }
     }
-    __syncthreads();
+    wave_sync();
     for (int mi = 0; mi < M; mi++) {
         const int n = uniform_i32(c.nreq[M - 1 - mi]);
         for (int i = 0; i < W; i++) {
@@ -1218,7 +1228,7 @@ __device__ __forceinline__ void build_field(Ctx &c, const PathRef &p, uint64_t f
             if (((w >> c.lane) & 1ull) && sl < S) needx[2 * sl + n] = 1;
         }
     }
-    __syncthreads();
+    wave_sync();
     int nxl = 0;
     for (int x0 = 0; x0 < nx; x0 += kWave) {
         const int x = x0 + c.lane;
@@ -1227,7 +1237,7 @@ __device__ __forceinline__ void build_field(Ctx &c, const PathRef &p, uint64_t f
         if (need) xlist[nxl + __popcll((unsigned long long)(bal & lanes_below(c.lane)))] = (uint16_t)x;
         nxl += __popcll((unsigned long long)bal);
     }
-    __syncthreads();
+    wave_sync();
     for (int base = 0; base < L; base += kWave) {
         const int j = base + c.lane;
         int c2k = 0, nk = 0;
@@ -1293,8 +1303,8 @@ __device__ __forceinline__ void build_field(Ctx &c, const PathRef &p, uint64_t f
             if (live) Fx[x] += f;
         }
     }
-    __syncthreads();
-    __syncthreads();
+    wave_sync();
+    wave_sync();
 }
 
 template <bool R32>
@@ -1514,7 +1524,7 @@ __device__ __forceinline__ void load_state(Ctx &c) {
     c.node_cum_reg = (c.lane < P.n_nodes && P.n_nodes <= kWave) ? P.node_cum[c.lane] : INFINITY;
     c.br_cum_reg = (c.lane < P.n_bit_rates && P.n_bit_rates <= kWave) ? P.bit_rate_cum[c.lane] : INFINITY;
     c.br_reg = (c.lane < P.n_bit_rates && P.n_bit_rates <= kWave) ? (float)P.bit_rates[c.lane] : 0.f;
-    __syncthreads();
+    wave_sync();
     c.active = c.e->st.active;
     c.osnr_prod = c.e->osnr_prod > 0.0 ? c.e->osnr_prod : 1.0;
     c.pre_id = -1;
@@ -1531,7 +1541,7 @@ __device__ __forceinline__ void load_state(Ctx &c) {
     for (int i = c.lane; i < c.active; i += kWave) { c.sa[i] = P.svc_a[off + i]; c.sb[i] = P.svc_b[off + i]; c.sr[i] = P.svc_r[off + i]; }
     if (P.defragmentation)
         for (int i = c.lane; i < c.active; i += kWave) { c.sq[i] = P.svc_q[off + i]; c.so[i] = P.svc_o[off + i]; }
-    __syncthreads();
+    wave_sync();
 }
 
 __device__ __forceinline__ void store_state(Ctx &c) {
@@ -1550,7 +1560,7 @@ __device__ __forceinline__ void store_state(Ctx &c) {
         c.e->st.total_path_hops += c.path_hops;
         c.e->st.total_active_sum += c.active_sum;
     }
-    __syncthreads();
+    wave_sync();
     uint64_t *ge = reinterpret_cast<uint64_t *>(P.env + c.replica);
     const uint64_t *le = reinterpret_cast<const uint64_t *>(c.e);
     for (int i = c.lane; i < (int)(kEnvHotBytes / 8); i += kWave) ge[i] = le[i];

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(64, WAVES) void k_run(const Params *__restrict__ Pp
                            rec->flags = ONGYM_F_NO_REQUEST; rec->active = c.active; }
                 if (mode == kModePolicyOnly) { act_out[c.replica] = -1; if (flag_out) flag_out[c.replica] = ONGYM_F_NO_REQUEST; }
             }
-            __syncthreads();
+            wave_sync();
             continue;
         }
         int src = e->cur_src, dst = e->cur_dst;
