@@ -283,6 +283,39 @@ def test_full_batch_invariants_nsfnet_4096():
     assert c.stats()["services_accepted"].tobytes() != sa["services_accepted"].tobytes()
 
 
+def test_bench_size_batch_65536_properties_and_sampled_oracle():
+    """The bench configuration itself (NSFNET-320, B = 65 536, capacity 448, 250 steps per launch): no overflow, launch
+    partition independence and conservation over the whole batch; state consistency and an oracle replay of the same
+    (seed, replica) streams on sampled replicas."""
+    tb = golden_tables("nsfnet")
+    B, steps = 65536, 1250
+    kw = dict(tables=tb, modulations=jocn_modulations(), batch_size=B, num_spectrum_resources=320, capacity=448,
+              load=300, bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), episode_length=1000)
+    a = BatchedQRMSAEnv(**kw); a.seed(1); a.reset()
+    for _ in range(steps // 250):
+        a.step_policy(250, record=False)
+    sa = a.stats()
+    assert not (sa["flags"] & nat.F_OVERFLOW).any() and sa["active"].max() < 448
+    assert (sa["total_steps"] == steps).all() and (sa["episodes_completed"] == 1).all()
+    assert (sa["episode_services_accepted"] + sa["rejected"] == sa["episode_services_processed"] - 1).all()
+    assert 0.005 < 1 - sa["total_accepted"].sum() / sa["total_steps"].sum() < 0.02
+    b = BatchedQRMSAEnv(**kw); b.seed(1); b.reset(); b.step_policy(steps, record=False)
+    assert b.stats().tobytes() == sa.tobytes()
+    holder = nat.ConfigHolder(tb, modulations=jocn_modulations(), num_spectrum_resources=320, batch=B, capacity=448,
+                              load=300, bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), episode_length=1000,
+                              auto_reset=True)
+    for r in (0, 1, 31337, B - 1):
+        check_state_invariants(a, tb, r, 320)
+        o = OracleEnv(holder, replica=r)
+        o.seed(1); o.reset(); o.run_first_fit(steps)
+        so = o.stats()
+        for f in ("services_accepted", "episode_services_accepted", "rejected", "bit_rate_provisioned", "active",
+                  "current_time", "last_episode_accepted", "last_service_blocking_rate", "total_paths_tried"):
+            assert sa[r][f] == so[f], (r, f)
+        assert sa[r]["last_mean_gsnr"] == pytest.approx(so["last_mean_gsnr"], rel=1e-9)
+        np.testing.assert_array_equal(a.grid(r), o.grid())
+
+
 @pytest.mark.parametrize("tag", ["traj_nsfnet320_lb", "traj_nobeleu320_lb", "traj_nsfnet128_hsnr"])
 def test_other_fused_policies_vs_reference(tag):
     """fused load_balancing_best_modulation (heuristics.py:547-627) / heuristic_highest_snr (:272-328) against the
