@@ -371,7 +371,6 @@ static int build(ongym_env *env, const ongym_config *c) {
     P.uniform_alpha = uniform ? 1 : 0;
     if (c->measure_disruptions && !uniform) return fail_arg(env, "measure_disruptions needs uniform attenuation", ONGYM_E_LIMIT);
     if (c->defragmentation && !uniform) return fail_arg(env, "defragmentation needs uniform attenuation", ONGYM_E_LIMIT);
-    if (c->defragmentation && c->capacity > 65535) return fail_arg(env, "defragmentation needs capacity <= 65535", ONGYM_E_LIMIT);
     P.rec32 = (E <= 32 && NP <= 512 && c->n_slots <= 1023) ? 1 : 0;
     P.alpha0_cl = cl[0];
     std::vector<uint64_t> mask((size_t)NP * 2, 0);

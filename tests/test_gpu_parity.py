@@ -515,3 +515,40 @@ def test_defragmentation_random_traffic_vs_oracle(n_defrag, topo, S, load):
         np.testing.assert_allclose(a["osnr"], b["osnr"], rtol=GSNR_RTOL)
         moved += int(so["last_episode_service_reallocations"])
     assert moved > 50
+
+
+def test_c_abi_rejects_bad_arguments_without_touching_the_device():
+    """Every operand of a query / step is validated on the host before a launch (include/ongym.h: errors are codes +
+    ongym_last_error, nothing throws, nothing out of range reaches a kernel)."""
+    import copy
+    meta, d = load_traj("traj_nsfnet320")
+    env = make_env(meta, batch=2)
+    with pytest.raises(OngymError, match="no request source"):
+        env.reset()
+    env.seed(3); env.reset(); env.step_policy(50, record=False)
+    P = golden_tables("nsfnet").n_paths
+    for bad in ([(P, 0, 4)], [(-1, 0, 4)], [(0, -1, 4)], [(0, 0, 0)], [(0, 318, 4)], [(0, 0, 4), (0, 320, 1)]):
+        with pytest.raises(OngymError, match="out of"):
+            env.gsnr_many(0, bad)
+    with pytest.raises(OngymError, match="replica out of range"):
+        env.gsnr_many(2, [(0, 0, 4)])
+    assert env.gsnr_many(0, np.zeros((0, 3), np.int32)).shape == (0, 3)
+    with pytest.raises(OngymError, match="replica out of range"):
+        env.grid(5)
+    with pytest.raises(OngymError, match="path id out of range"):
+        env.available_slots(0, P)
+    with pytest.raises(OngymError, match="unknown policy"):
+        env.step_policy(1, policy=7)
+    with pytest.raises(OngymError, match="nsteps"):
+        env.step_policy(0)
+    moves, total = env.moves(0)                       # defragmentation is off: empty, not an error
+    assert total == 0 and len(moves) == 0
+    # create-time limits
+    tb = copy.deepcopy(golden_tables("nsfnet"))
+    tb.link_alpha = tb.link_alpha.copy(); tb.link_alpha[3] *= 1.1
+    for kw in (dict(defragmentation=True), dict(measure_disruptions=True)):
+        with pytest.raises(OngymError, match="uniform attenuation"):
+            BatchedQRMSAEnv(tables=tb, modulations=jocn_modulations(), batch_size=1, load=100,
+                            bit_rate_selection="discrete", bit_rates=(10, 40), **kw)
+    with pytest.raises(OngymError, match="n_defrag_services"):
+        make_env(meta, defragmentation=True, n_defrag_services=-1)
