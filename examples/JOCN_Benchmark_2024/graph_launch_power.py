@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Launch-power sweep of the JOCN benchmark (Sec. 4.A of the paper; reference: examples/JOCN_Benchmark_2024/
 graph_launch_power.py), batched: the 17 launch powers x R parallel simulations are replicas of ONE device environment.
+Heuristic indices are the reference's (graph_launch_power.py:106-128); all but 5 (full MSCL, plugin only) are fused on
+device.
 
     python examples/JOCN_Benchmark_2024/graph_launch_power.py -t nobel-eu.xml -e 1000 -s 1000 -l 200
 """
@@ -8,7 +10,10 @@ import argparse
 
 import numpy as np
 
-from jocn_common import load_topology, run_sweep
+from jocn_common import load_topology, run_sweep, run_sweep_plugin
+
+# reference index -> fused device policy id (include/ongym.h)
+FUSED = {1: 0, 2: 3, 3: 5, 4: 1, 6: 6, 7: 7, 8: 4, 9: 8, 10: 8}
 
 
 def main():
@@ -20,6 +25,10 @@ def main():
     ap.add_argument("-th", "--threads", type=int, default=64, help="parallel simulations (replicas) per launch power")
     ap.add_argument("-k", "--k_paths", type=int, default=5)
     ap.add_argument("-mf", "--monitor_file_name", default="examples/JOCN_Benchmark_2024/results/simulation_results")
+    ap.add_argument("-hi", "--heuristic_index", type=int, default=1, choices=[1, 2, 3, 4, 5, 6, 7, 8, 9, 10],
+                    help="1 first fit, 2 lowest spectrum, 3 best-modulation load balancing, 4 load balancing best "
+                         "modulation, 5 MSCL (plugin), 6 MSCL simplified, 7 MSCL sequential, 8 load-balancing first fit, "
+                         "9 PSR-C, 10 PSR-O")
     ap.add_argument("--slots", type=int, default=320)
     ap.add_argument("--seed", type=int, default=20)
     args = ap.parse_args()
@@ -29,9 +38,17 @@ def main():
     common = dict(load=float(args.load), num_spectrum_resources=args.slots, bit_rate_selection="discrete",
                   bit_rates=(10, 40, 100, 400), capacity=1024)
     names = [f"{args.monitor_file_name}_{topology.graph['name']}_{lp}_{float(args.load)}.csv" for lp in launch_powers]
+    points = [dict(launch_power_dbm=float(lp)) for lp in launch_powers]
+    if args.heuristic_index == 5:
+        from optical_networking_gym.heuristics.heuristics import heuristic_mscl
+        res = run_sweep_plugin(topology, heuristic_mscl, n_episodes=args.num_episodes, episode_length=args.episode_length,
+                               seed=args.seed, common=common, points=points, monitor_names=names)
+        for lp, b in zip(launch_powers, res):
+            print(f"Launch power: {lp:.1f} dBm, mean: {b.mean():.4f}")
+        return
     res = run_sweep(topology, n_episodes=args.num_episodes, episode_length=args.episode_length,
                     replicas_per_point=min(args.threads, args.num_episodes), seed=args.seed, common=common,
-                    points=[dict(launch_power_dbm=float(lp)) for lp in launch_powers], monitor_names=names)
+                    points=points, monitor_names=names, policy=FUSED[args.heuristic_index])
     for lp, b in zip(launch_powers, res):
         print(f"Launch power: {lp:.1f} dBm, mean: {b.mean():.4f}, stdev: {b.std(ddof=1) if len(b) > 1 else 0:.4f}")
 

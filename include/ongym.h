@@ -39,8 +39,18 @@ enum {
 enum {
     ONGYM_POLICY_FIRST_FIT = 0,      /* heuristic_shortest_available_path_first_fit_best_modulation, heuristics.py:923-966 */
     ONGYM_POLICY_LOAD_BALANCING = 1, /* load_balancing_best_modulation, heuristics.py:547-627 (graph_load.py heuristic 4) */
-    ONGYM_POLICY_HIGHEST_SNR = 2     /* heuristic_highest_snr, heuristics.py:272-328 (graph_load.py heuristic 2); needs
+    ONGYM_POLICY_HIGHEST_SNR = 2,    /* heuristic_highest_snr, heuristics.py:272-328 (graph_load.py heuristic 2); needs
                                         uniform attenuation */
+    /* the cheaper remaining policies of heuristics.py, one shared kernel instantiation (graph_launch_power.py 2,3,6,7,9): */
+    ONGYM_POLICY_LOWEST_SPECTRUM = 3, /* shortest_available_path_lowest_spectrum_best_modulation, :431-490 */
+    ONGYM_POLICY_LB_FIRST_FIT = 4,    /* heuristic_load_balancing_first_fit, :202-269 */
+    ONGYM_POLICY_BEST_MOD_LB = 5,     /* best_modulation_load_balancing, :491-545 */
+    ONGYM_POLICY_MSCL_SIMPLIFIED = 6, /* heuristic_mscl_simplified, :765-839 */
+    ONGYM_POLICY_MSCL_SEQUENTIAL = 7, /* heuristic_mscl_sequential_simplified, :841-921 */
+    ONGYM_POLICY_PSR = 8,             /* heuristic_psr with its default coefficients, :1019-1119 */
+    ONGYM_POLICY_EXACT_FIT = 9,       /* heuristic_exact_fit, :1121-1227 (asks for no guard slot: the step may answer
+                                         with the occupied-slots penalty, retry = 1) */
+    ONGYM_POLICY_COUNT = 10
 };
 
 /* ongym_step_rec.flags */

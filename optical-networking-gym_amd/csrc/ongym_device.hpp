@@ -530,6 +530,7 @@ struct Choice {
     int hops, mylink;   // chosen path as lanes see it
     uint64_t m0;        // its link mask (low word)
     GnLin g;
+    int busy = 0;       // exact fit only: the proposed slots lack the guard slot -> the step answers with the penalty
 };
 
 // ---- heuristic_shortest_available_path_first_fit_best_modulation (heuristics/heuristics.py:923-966) -----------
@@ -684,6 +685,191 @@ __device__ __forceinline__ int evaluate_action(Ctx &c, int src, int dst, double 
     GnLin g = gn_eval<UNIFORM_ALPHA, R32>(c, p, L, slot, n);
     ch.g.ase = uniform_f64(g.ase); ch.g.nli = uniform_f64(g.nli);
     return qot_ok(c, g, m, margin) ? 0 : 3;
+}
+
+// ---- the cheaper remaining policies of heuristics/heuristics.py, one function (policy id is wave-uniform) -------------
+// lowest spectrum (:431-490), load-balancing first fit (:202-269), best-modulation load balancing (:491-545), simplified
+// MSCL (:765-839) and its sequential variant (:841-921), PSR with default coefficients (:1019-1119), exact fit
+// (:1121-1227). All reuse the bitmap scan and the GN evaluation of the first-fit path; none is on the benchmark path, so
+// they take the full GN evaluation for every candidate (no lower-bound shortcut).
+__device__ __forceinline__ bool any_bits(uint64_t x) { return __ballot(x != 0) != 0; }
+
+// multiword logical shift right by s >= 1 of a lane-distributed bitmap (word w in lane w < 16, zeros elsewhere)
+__device__ __forceinline__ uint64_t shift_right(uint64_t x, int s) {
+    if (s < 64) return (x >> s) | (next_word(x) << (64 - s));
+    const int q = s >> 6, t = s & 63;
+    const uint64_t a = __shfl_down((unsigned long long)x, q), b = __shfl_down((unsigned long long)x, q + 1);
+    return t ? ((a >> t) | (b << (64 - t))) : a;
+}
+// multiword shift left by one
+__device__ __forceinline__ uint64_t shift_left1(uint64_t x) {
+    const uint64_t prev = __shfl_up((unsigned long long)x, 1);
+    return (x << 1) | (threadIdx.x > 0 ? prev >> 63 : 0ull);
+}
+// longest run of set bits (_get_largest_contiguous_block, :751-763): largest m with a window of m ones, by doubling
+// then binary refinement of the run-AND
+__device__ __forceinline__ int longest_run(uint64_t x) {
+    if (!any_bits(x)) return 0;
+    uint64_t y = x;
+    int r = 1;
+    for (;;) {
+        int r2 = r;
+        const uint64_t y2 = run_and(y, r2, 2 * r);
+        if (!any_bits(y2)) break;
+        y = y2; r = r2;
+    }
+    for (int step = r >> 1; step >= 1; step >>= 1) {
+        int r2 = r;
+        const uint64_t y2 = run_and(y, r2, r + step);
+        if (any_bits(y2)) { y = y2; r = r2; }
+    }
+    return r;   // doubling found the largest power of two with a run, the halving steps the exact maximum
+}
+
+__device__ __forceinline__ int path_free_count(const Ctx &c, uint64_t row) {   // free slots of a row (no virtual bit)
+    int cnt = c.lane < c.P.row_words ? __popcll((unsigned long long)row) : 0;
+#pragma unroll
+    for (int mm = 8; mm >= 1; mm >>= 1) cnt += __shfl_xor(cnt, mm);
+    return uniform_i32(cnt);
+}
+
+template <bool UNIFORM_ALPHA, bool R32>
+__device__ __forceinline__ void policy_misc(Ctx &c, int policy, int src, int dst, double margin, Choice &ch) {
+    const Params &P = c.P;
+    const int M = P.n_mods, S = P.n_slots, max_mod = M - 1, K = P.k_paths;
+    ch.action = K * M * S; ch.route = -1; ch.mod = -1; ch.slot = -1; ch.n = 0; ch.hops = 0; ch.mylink = 0;
+    ch.path = -1; ch.m0 = 0; ch.g.ase = ch.g.nli = 0.0; ch.flags = 0;
+    int bres = 0, bosnr = 0;
+    int best_score = -1;
+    auto take = [&](int k, int m, int slot, int n, const PathRef &p, const GnLin &g) {
+        ch.action = k * M * S + (max_mod - m) * S + slot;
+        ch.route = k; ch.mod = m; ch.slot = slot; ch.n = n; ch.hops = p.hops; ch.mylink = p.mylink;
+        ch.path = p.id; ch.m0 = p.m0;
+        ch.g.ase = uniform_f64(g.ase); ch.g.nli = uniform_f64(g.nli);
+    };
+    auto row_of = [&](uint64_t free_ext) {   // the path row without the virtual free slot S
+        return (c.lane == (S >> 6)) ? (free_ext & ~(1ull << (S & 63))) : free_ext;
+    };
+    auto path_at = [&](int k, PathRef &p) -> bool {
+        const int path = uniform_i32(G(P.pair_paths)[(src * P.n_nodes + dst) * K + k]);
+        if (path < 0) return false;
+        p = load_path(c, path);
+        return true;
+    };
+
+    if (policy == ONGYM_POLICY_BEST_MOD_LB) {
+        // modulations outer (all of them), routes inner; first free run of >= n+1 slots INSIDE the row (no edge waiver)
+        for (int m = M - 1; m >= 0; m--) {
+            const int n = uniform_i32(c.nreq[m]);
+            if (n <= 0) continue;
+            for (int k = 0; k < K; k++) {
+                PathRef p;
+                if (!path_at(k, p)) break;
+                int rr = 1;
+                const int slot = first_set(run_and(row_of(path_free_ext(c, p)), rr, n + 1));
+                if (slot < 0) continue;
+                const int L = gn_build_list<R32>(c, p.m0, p.m1);
+                const GnLin g = gn_eval<UNIFORM_ALPHA, R32>(c, p, L, slot, n);
+                if (qot_ok(c, g, m, margin)) { take(k, m, slot, n, p, g); return; }
+            }
+        }
+        return;   // (reject, False, False)
+    }
+
+    // route order: natural, or by (busy slots, index) for load-balancing first fit
+    int order[8];
+    int nk = 0;
+    for (int k = 0; k < K && k < 8; k++) order[k] = k;
+    if (policy == ONGYM_POLICY_LB_FIRST_FIT) {
+        int busy[8];
+        for (int k = 0; k < K && k < 8; k++) {
+            PathRef p;
+            if (!path_at(k, p)) break;
+            busy[k] = S - path_free_count(c, row_of(path_free_ext(c, p)));
+            nk++;
+        }
+        for (int i = 1; i < nk; i++)
+            for (int j = i; j > 0 && busy[order[j]] < busy[order[j - 1]]; j--) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    } else {
+        nk = K < 8 ? K : 8;
+    }
+
+    for (int i = 0; i < nk; i++) {
+        const int k = order[i];
+        PathRef p;
+        if (!path_at(k, p)) break;
+        const uint64_t free_ext = path_free_ext(c, p);
+        const uint64_t row = row_of(free_ext);
+        int L = -1;
+        if (policy == ONGYM_POLICY_MSCL_SEQUENTIAL) best_score = -1;
+        const bool row_empty = !any_bits(row);
+        for (int m = max_mod; m >= 0; m--) {
+            const int n = uniform_i32(c.nreq[m]);
+            if (n <= 0) continue;
+            if (policy == ONGYM_POLICY_EXACT_FIT) {
+                if (row_empty) { bres = 1; continue; }
+                // walk the free runs left to right: first of length == n, else the smallest >= n (first among equals)
+                uint64_t y = row;
+                int exact = -1, fit = -1, fit_len = 0x7fffffff;
+                for (;;) {
+                    const int s0 = first_set(y);
+                    if (s0 < 0) break;
+                    int e0 = first_set(~row & word_range(c.lane, s0, S));
+                    if (e0 < 0) e0 = S;
+                    const int len = e0 - s0;
+                    if (len == n) { exact = s0; break; }
+                    if (len >= n && len < fit_len) { fit_len = len; fit = s0; }
+                    y &= ~word_range(c.lane, s0, e0);
+                }
+                const int slot = exact >= 0 ? exact : fit;
+                if (slot < 0) { bres = 1; continue; }
+                if (L < 0) L = gn_build_list<R32>(c, p.m0, p.m1);
+                const GnLin g = gn_eval<UNIFORM_ALPHA, R32>(c, p, L, slot, n);
+                if (qot_ok(c, g, m, margin)) {
+                    take(k, m, slot, n, p, g);
+                    int rr = 1;                                    // is_path_free (envs/qrmsa.pyx:1248-1264) wants the guard
+                    const uint64_t okb = run_and(free_ext, rr, n + 1);
+                    const uint64_t w = readlane_u64(okb, uniform_i32(slot >> 6));
+                    ch.busy = !((w >> (slot & 63)) & 1ull);
+                    return;
+                }
+                bosnr = 1;
+                continue;
+            }
+            int rr = 1;
+            uint64_t v = run_and(free_ext, rr, n + 1);             // _get_candidates
+            if (policy == ONGYM_POLICY_PSR) {
+                for (;;) {                                         // every start of this modulation, lowest first
+                    const int s0 = first_set(v);
+                    if (s0 < 0) break;
+                    if (L < 0) L = gn_build_list<R32>(c, p.m0, p.m1);
+                    const GnLin g = gn_eval<UNIFORM_ALPHA, R32>(c, p, L, s0, n);
+                    if (qot_ok(c, g, m, margin)) { take(k, m, s0, n, p, g); return; }
+                    if (c.lane == (s0 >> 6)) v &= ~(1ull << (s0 & 63));
+                }
+                continue;
+            }
+            const int first = first_set(v);
+            if (first < 0) { bres = 1; continue; }
+            if (L < 0) L = gn_build_list<R32>(c, p.m0, p.m1);
+            const GnLin g = gn_eval<UNIFORM_ALPHA, R32>(c, p, L, first, n);
+            const int ok = qot_ok(c, g, m, margin);
+            if (policy == ONGYM_POLICY_MSCL_SIMPLIFIED || policy == ONGYM_POLICY_MSCL_SEQUENTIAL) {
+                if (ok) {   // score: the longest free run left on the route once [first, first+n) is taken (no guard)
+                    const int score = longest_run(row & ~word_range(c.lane, first, first + n));
+                    if (score > best_score) { best_score = score; take(k, m, first, n, p, g); }
+                } else bosnr = 1;
+                continue;
+            }
+            if (ok) { take(k, m, first, n, p, g); return; }        // lowest spectrum / load-balancing first fit
+            bosnr = 1;
+        }
+        if (policy == ONGYM_POLICY_MSCL_SEQUENTIAL && ch.route >= 0) return;
+    }
+    if (ch.route >= 0) return;                                     // simplified MSCL: best over all routes
+    if (policy == ONGYM_POLICY_PSR || policy == ONGYM_POLICY_LB_FIRST_FIT) { ch.flags = ONGYM_F_BLOCKED_RESOURCES; return; }
+    if ((policy == ONGYM_POLICY_LOWEST_SPECTRUM || policy == ONGYM_POLICY_EXACT_FIT) && bosnr) bres = 0;
+    ch.flags = (bres ? ONGYM_F_BLOCKED_RESOURCES : 0) | (bosnr ? ONGYM_F_BLOCKED_OSNR : 0);
 }
 
 // ---- departures: release every running service with float32 key <= now (envs/qrmsa.pyx:1113-1122, 1332-1350) ---

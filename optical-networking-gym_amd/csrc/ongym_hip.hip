@@ -18,9 +18,11 @@ using namespace ongym;
 // ---------------------------------------------------------------------------------------------------------------
 // WAVES = waves per SIMD the register allocation is bounded for: 5 when the replica's LDS block is <= 8 KiB (20 replicas
 // per CU), else 4
+constexpr int kPolicyMisc = 3;   // template value of the shared instantiation for policy ids >= ONGYM_POLICY_LOWEST_SPECTRUM
+
 template <bool UA, bool R32, int WAVES, int POLICY, bool DEFRAG = false>
 __global__ __launch_bounds__(64, WAVES) void k_run(const Params *__restrict__ Pp, int mode, int nsteps, const int32_t *actions, int32_t *act_out,
-                                            uint8_t *flag_out, ongym_step_rec *out) {
+                                            uint8_t *flag_out, ongym_step_rec *out, int policy_id) {
     extern __shared__ __align__(16) unsigned char smem[];
     const Params &P = *Pp;
     Ctx c(P);
@@ -68,8 +70,9 @@ __global__ __launch_bounds__(64, WAVES) void k_run(const Params *__restrict__ Pp
         } else {
             if (POLICY == ONGYM_POLICY_HIGHEST_SNR) policy_highest_snr<R32>(c, src, dst, lp, mg, ch);
             else if (POLICY == ONGYM_POLICY_LOAD_BALANCING) policy_load_balancing<UA, R32>(c, src, dst, lp, mg, ch);
+            else if (POLICY == kPolicyMisc) policy_misc<UA, R32>(c, policy_id, src, dst, mg, ch);
             else policy_first_fit<UA, R32>(c, src, dst, lp, mg, ch);
-            outcome = ch.route >= 0 ? 0 : 1;
+            outcome = ch.route >= 0 ? (ch.busy ? 2 : 0) : 1;
         }
         if (mode == kModePolicyOnly) {
             if (c.lane == 0) { act_out[c.replica] = ch.action; if (flag_out) flag_out[c.replica] = (uint8_t)ch.flags; }
@@ -532,9 +535,12 @@ static int build(ongym_env *env, const ongym_config *c) {
         ONGYM_SET_LDS((k_run<false, true, 4, 0>)); ONGYM_SET_LDS((k_run<false, false, 4, 0>));
         ONGYM_SET_LDS((k_run<true, true, 4, 1>)); ONGYM_SET_LDS((k_run<true, false, 4, 1>));
         ONGYM_SET_LDS((k_run<false, true, 4, 1>)); ONGYM_SET_LDS((k_run<false, false, 4, 1>));
+        ONGYM_SET_LDS((k_run<true, true, 4, kPolicyMisc>)); ONGYM_SET_LDS((k_run<true, false, 4, kPolicyMisc>));
+        ONGYM_SET_LDS((k_run<false, true, 4, kPolicyMisc>)); ONGYM_SET_LDS((k_run<false, false, 4, kPolicyMisc>));
         if (P.defragmentation) {
             ONGYM_SET_LDS((k_run<true, true, 4, 0, true>)); ONGYM_SET_LDS((k_run<true, false, 4, 0, true>));
             ONGYM_SET_LDS((k_run<true, true, 4, 1, true>)); ONGYM_SET_LDS((k_run<true, false, 4, 1, true>));
+            ONGYM_SET_LDS((k_run<true, true, 4, kPolicyMisc, true>)); ONGYM_SET_LDS((k_run<true, false, 4, kPolicyMisc, true>));
         }
         ONGYM_SET_LDS((k_query<true, true>)); ONGYM_SET_LDS((k_query<true, false>));
         ONGYM_SET_LDS((k_query<false, true>)); ONGYM_SET_LDS((k_query<false, false>));
@@ -714,7 +720,7 @@ static int launch_run(ongym_env *env, int mode, int policy, int nsteps, const in
     }
 #define ONGYM_LAUNCH_DEFRAG(R, POL, LDS)                                                                           \
     hipLaunchKernelGGL((k_run<true, R, 4, POL, true>), grid, block, LDS, env->stream, env->d_P, mode, nsteps,      \
-                       d_actions, d_act_out, d_flag_out, d_out)
+                       d_actions, d_act_out, d_flag_out, d_out, policy)
     if (env->P.defragmentation) {   // defragmentation (needs uniform attenuation, checked at create): own instantiations
         if (policy == ONGYM_POLICY_HIGHEST_SNR) {
             if (field_lds(env) > 64 * 1024) {
@@ -726,6 +732,9 @@ static int launch_run(ongym_env *env, int mode, int policy, int nsteps, const in
         } else if (policy == ONGYM_POLICY_LOAD_BALANCING) {
             if (env->P.rec32) ONGYM_LAUNCH_DEFRAG(true, ONGYM_POLICY_LOAD_BALANCING, env->lds);
             else ONGYM_LAUNCH_DEFRAG(false, ONGYM_POLICY_LOAD_BALANCING, env->lds);
+        } else if (policy >= ONGYM_POLICY_LOWEST_SPECTRUM) {
+            if (env->P.rec32) ONGYM_LAUNCH_DEFRAG(true, kPolicyMisc, env->lds);
+            else ONGYM_LAUNCH_DEFRAG(false, kPolicyMisc, env->lds);
         } else {
             if (env->P.rec32) ONGYM_LAUNCH_DEFRAG(true, ONGYM_POLICY_FIRST_FIT, env->lds);
             else ONGYM_LAUNCH_DEFRAG(false, ONGYM_POLICY_FIRST_FIT, env->lds);
@@ -740,16 +749,19 @@ static int launch_run(ongym_env *env, int mode, int policy, int nsteps, const in
     do {                                                                                                           \
         if (policy == ONGYM_POLICY_HIGHEST_SNR)                                                                    \
             hipLaunchKernelGGL((k_run<true, R, 4, ONGYM_POLICY_HIGHEST_SNR>), grid, block, field_lds(env),          \
-                               env->stream, env->d_P, mode, nsteps, d_actions, d_act_out, d_flag_out, d_out);      \
+                               env->stream, env->d_P, mode, nsteps, d_actions, d_act_out, d_flag_out, d_out, policy);      \
         else if (policy == ONGYM_POLICY_LOAD_BALANCING)                                                            \
             hipLaunchKernelGGL((k_run<UA, R, 4, ONGYM_POLICY_LOAD_BALANCING>), grid, block, env->lds, env->stream,  \
-                               env->d_P, mode, nsteps, d_actions, d_act_out, d_flag_out, d_out);                   \
+                               env->d_P, mode, nsteps, d_actions, d_act_out, d_flag_out, d_out, policy);                   \
+        else if (policy >= ONGYM_POLICY_LOWEST_SPECTRUM)                                                           \
+            hipLaunchKernelGGL((k_run<UA, R, 4, kPolicyMisc>), grid, block, env->lds, env->stream,                  \
+                               env->d_P, mode, nsteps, d_actions, d_act_out, d_flag_out, d_out, policy);                   \
         else if (env->lds <= 8192)                                                                                 \
             hipLaunchKernelGGL((k_run<UA, R, 5, ONGYM_POLICY_FIRST_FIT>), grid, block, env->lds, env->stream,       \
-                               env->d_P, mode, nsteps, d_actions, d_act_out, d_flag_out, d_out);                   \
+                               env->d_P, mode, nsteps, d_actions, d_act_out, d_flag_out, d_out, policy);                   \
         else                                                                                                       \
             hipLaunchKernelGGL((k_run<UA, R, 4, ONGYM_POLICY_FIRST_FIT>), grid, block, env->lds, env->stream,       \
-                               env->d_P, mode, nsteps, d_actions, d_act_out, d_flag_out, d_out);                   \
+                               env->d_P, mode, nsteps, d_actions, d_act_out, d_flag_out, d_out, policy);                   \
     } while (0)
     if (env->P.uniform_alpha) { if (env->P.rec32) ONGYM_LAUNCH_RUN(true, true); else ONGYM_LAUNCH_RUN(true, false); }
     else { if (env->P.rec32) ONGYM_LAUNCH_RUN(false, true); else ONGYM_LAUNCH_RUN(false, false); }
@@ -770,7 +782,9 @@ static int ensure_out(ongym_env *env, size_t n) {
 
 int ongym_step_policy(ongym_env *env, int32_t policy, int32_t nsteps, ongym_step_rec *out) {
     if (!env) return ONGYM_E_ARG;
-    if (policy < ONGYM_POLICY_FIRST_FIT || policy > ONGYM_POLICY_HIGHEST_SNR) return fail_arg(env, "unknown policy id");
+    if (policy < ONGYM_POLICY_FIRST_FIT || policy >= ONGYM_POLICY_COUNT) return fail_arg(env, "unknown policy id");
+    if (policy >= ONGYM_POLICY_LOWEST_SPECTRUM && env->P.k_paths > 8)
+        return fail_arg(env, "this policy supports at most 8 candidate routes", ONGYM_E_LIMIT);
     if (nsteps <= 0) return fail_arg(env, "nsteps must be positive");
     if (!env->has_source) { env->err = "no request source: call ongym_seed or ongym_set_requests first"; return ONGYM_E_STATE; }
     HIP_TRY(env, hipSetDevice(env->cfg.device));
@@ -843,7 +857,9 @@ int ongym_observe(ongym_env *env, float *obs, uint8_t *mask) {
 
 int ongym_policy_actions(ongym_env *env, int32_t policy, int32_t *actions, uint8_t *flags) {
     if (!env || !actions) return env ? fail_arg(env, "null actions") : ONGYM_E_ARG;
-    if (policy < ONGYM_POLICY_FIRST_FIT || policy > ONGYM_POLICY_HIGHEST_SNR) return fail_arg(env, "unknown policy id");
+    if (policy < ONGYM_POLICY_FIRST_FIT || policy >= ONGYM_POLICY_COUNT) return fail_arg(env, "unknown policy id");
+    if (policy >= ONGYM_POLICY_LOWEST_SPECTRUM && env->P.k_paths > 8)
+        return fail_arg(env, "this policy supports at most 8 candidate routes", ONGYM_E_LIMIT);
     HIP_TRY(env, hipSetDevice(env->cfg.device));
     int rc;
     if (env->cfg.io_device) return launch_run(env, kModePolicyOnly, policy, 1, nullptr, actions, flags, nullptr);

@@ -128,7 +128,7 @@ def _osnr_at(sim_env, path, modulation, slot, slots) -> float:
     return calculate_osnr(sim_env, service)[0]
 
 
-def shortest_available_path_lowest_spectrum_best_modulation(env):
+def shortest_available_path_lowest_spectrum_best_modulation_plugin(env):
     """Reference :431-490 — the first-fit walk; only the flag rule differs (an OSNR failure anywhere clears the
     resources flag at the end)."""
     sim_env = get_qrmsa_env(env)
@@ -143,7 +143,7 @@ def shortest_available_path_lowest_spectrum_best_modulation(env):
     return env.action_space.n - 1, (no_slots and not low_osnr), low_osnr
 
 
-def best_modulation_load_balancing(env):
+def best_modulation_load_balancing_plugin(env):
     """Reference :491-545 — modulations outer (ALL of them, most efficient first), routes inner; the first free run of
     at least slots+1 (no exception at the end of the spectrum) whose GSNR passes.  Never reports a blocking cause."""
     sim_env = get_qrmsa_env(env)
@@ -163,7 +163,7 @@ def best_modulation_load_balancing(env):
     return sim_env.reject_action, False, False
 
 
-def heuristic_load_balancing_first_fit(env):
+def heuristic_load_balancing_first_fit_plugin(env):
     """Reference :202-269 — routes sorted by (occupied fraction, route index), then first fit; (reject, True, False)."""
     sim_env = get_qrmsa_env(env)
     ranked = []
@@ -332,7 +332,7 @@ def _simplified_mscl_scores(sim_env, routes=None):
             yield path_idx, None, None, False, True
 
 
-def heuristic_mscl_simplified(env):
+def heuristic_mscl_simplified_plugin(env):
     """Reference :765-839 — over all routes and modulations, the first-fit candidate leaving the longest free run."""
     sim_env = get_qrmsa_env(env)
     best, best_score = None, -1
@@ -346,7 +346,7 @@ def heuristic_mscl_simplified(env):
     return sim_env.action_space.n - 1, no_slots, low_osnr
 
 
-def heuristic_mscl_sequential_simplified(env):
+def heuristic_mscl_sequential_simplified_plugin(env):
     """Reference :841-921 — the same score, but the first route with any passing candidate answers."""
     sim_env = get_qrmsa_env(env)
     no_slots = low_osnr = False
@@ -361,7 +361,7 @@ def heuristic_mscl_sequential_simplified(env):
     return sim_env.action_space.n - 1, no_slots, low_osnr
 
 
-def heuristic_psr(env, variant: str = "O", coef_dist: float = 1.0, coef_slots: float = 1.0):
+def heuristic_psr_plugin(env, variant: str = "O", coef_dist: float = 1.0, coef_slots: float = 1.0):
     """Power-series routing, reference :1019-1119.  The route cost (sum for 'C', product otherwise, over the route's
     links of coef_dist * length/longest and coef_slots / (placements of the most efficient format + 1)) only gates a
     route against `best_cost`, which stays infinite until the search ends at the first success — so the answer is the
@@ -393,7 +393,7 @@ def heuristic_psr(env, variant: str = "O", coef_dist: float = 1.0, coef_slots: f
     return sim_env.action_space.n - 1, True, False
 
 
-def heuristic_exact_fit(env):
+def heuristic_exact_fit_plugin(env):
     """Reference :1121-1227 — per (route, modulation): the first free run of EXACTLY the needed length, else the
     smallest run that is long enough (first among equals); then the QoT check.  No guard slot is asked for, so the env may
     answer such an action with the occupied-slots penalty (qrmsa.pyx:886-897)."""
@@ -485,3 +485,33 @@ def heuristic_highest_snr_plugin(env):
     if best is None:
         return env.action_space.n - 1, (no_slots and not low_osnr), low_osnr
     return best, False, False
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Public names -> the policies fused on device (one launch per decision; the same ids drive whole batched episodes through
+# BatchedQRMSAEnv.step_policy(policy=...)).  The `*_plugin` bodies above are the same policies written against the plugin
+# API only; tests hold both to the decisions captured from the reference.
+# ----------------------------------------------------------------------------------------------------------------------
+def _fused(policy_id, doc):
+    def call(env):
+        return get_qrmsa_env(env).policy_action(policy_id)
+    call.__doc__ = doc
+    return call
+
+
+shortest_available_path_lowest_spectrum_best_modulation = _fused(
+    _nat.POLICY_LOWEST_SPECTRUM, "Reference :431-490, fused on device (ONGYM_POLICY_LOWEST_SPECTRUM).")
+best_modulation_load_balancing = _fused(_nat.POLICY_BEST_MOD_LB, "Reference :491-545, fused on device.")
+heuristic_load_balancing_first_fit = _fused(_nat.POLICY_LB_FIRST_FIT, "Reference :202-269, fused on device.")
+heuristic_mscl_simplified = _fused(_nat.POLICY_MSCL_SIMPLIFIED, "Reference :765-839, fused on device.")
+heuristic_mscl_sequential_simplified = _fused(_nat.POLICY_MSCL_SEQUENTIAL, "Reference :841-921, fused on device.")
+heuristic_exact_fit = _fused(_nat.POLICY_EXACT_FIT, "Reference :1121-1227, fused on device.")
+
+
+def heuristic_psr(env, variant: str = "O", coef_dist: float = 1.0, coef_slots: float = 1.0):
+    """Reference :1019-1119.  With finite positive coefficients the route cost never changes the answer (see
+    `heuristic_psr_plugin`), which is then the fused device policy; anything else takes the literal plugin path."""
+    import math as _m
+    if all(_m.isfinite(v) and v > 0 for v in (coef_dist, coef_slots)):
+        return get_qrmsa_env(env).policy_action(_nat.POLICY_PSR)
+    return heuristic_psr_plugin(env, variant, coef_dist, coef_slots)

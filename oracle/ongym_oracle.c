@@ -584,9 +584,204 @@ int orc_policy_highest_snr(orc_env *e, int *blocked_resources, int *blocked_osnr
     return best_action;
 }
 
+/* ---- the cheaper remaining policies of heuristics/heuristics.py ------------------------------------------------------ */
+static int path_of(const orc_env *e, int k) {
+    return e->pair_paths[(e->cur.src * e->cfg.n_nodes + e->cur.dst) * e->cfg.k_paths + k];
+}
+static int passes(orc_env *e, int p, int slot, int n, int m) {
+    double o[3];
+    gn_state(e, p, slot, n, o, 1);
+    return o[0] >= e->mod_thr[m] + e->margin;
+}
+/* run-length view of a row (utils.rle, utils.pyx:44-58): starts/lengths of the FREE runs, left to right */
+static int free_runs(const int32_t *row, int S, int32_t *start, int32_t *len) {
+    int n = 0;
+    for (int j = 0; j < S;) {
+        if (row[j] == 0) { j++; continue; }
+        int b = j;
+        while (j < S && row[j] != 0) j++;
+        start[n] = b; len[n] = j - b; n++;
+    }
+    return n;
+}
+static int largest_free_run(const int32_t *row, int S) {             /* _get_largest_contiguous_block, :751-763 */
+    int best = 0, cur = 0;
+    for (int j = 0; j < S; j++) { cur = row[j] ? cur + 1 : 0; if (cur > best) best = cur; }
+    return best;
+}
+
+/* shortest_available_path_lowest_spectrum_best_modulation (:431-490): the first-fit walk, other flag rule */
+static int orc_policy_lowest_spectrum(orc_env *e, int *bres_out, int *bosnr_out) {
+    int bres = 0, bosnr = 0, S = e->cfg.n_slots;
+    int32_t *avail = e->scratch_avail;
+    for (int k = 0; k < e->cfg.k_paths; k++) {
+        int p = path_of(e, k);
+        if (p < 0) break;
+        for (int m = e->max_mod_idx; m >= 0; m--) {
+            int req = orc_number_slots(e, e->cur.bit_rate, m);
+            if (req <= 0) continue;
+            orc_available(e, p, avail);
+            int32_t first;
+            if (orc_candidates(avail, S, req, &first, 1) == 0) { bres = 1; continue; }
+            if (passes(e, p, first, req, m)) { *bres_out = 0; *bosnr_out = 0; return orc_encode_action(e, k, m, first); }
+            bosnr = 1;
+        }
+    }
+    if (bosnr) bres = 0;
+    *bres_out = bres; *bosnr_out = bosnr;
+    return orc_reject_action(e);
+}
+
+/* heuristic_load_balancing_first_fit (:202-269): routes by (occupied fraction, index), then first fit */
+static int orc_policy_lb_first_fit(orc_env *e, int *bres_out, int *bosnr_out) {
+    int S = e->cfg.n_slots, K = e->cfg.k_paths;
+    int32_t *avail = e->scratch_avail;
+    int order[64], busy[64], nk = 0;
+    for (int k = 0; k < K && k < 64; k++) {
+        int p = path_of(e, k);
+        if (p < 0) break;
+        orc_available(e, p, avail);
+        busy[k] = 0;
+        for (int j = 0; j < S; j++) busy[k] += (avail[j] == 0);
+        order[nk++] = k;
+    }
+    for (int i = 1; i < nk; i++)                                   /* stable insertion sort: (load, index) ascending */
+        for (int j = i; j > 0 && busy[order[j]] < busy[order[j - 1]]; j--) { int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    for (int i = 0; i < nk; i++) {
+        int k = order[i], p = path_of(e, k);
+        for (int m = e->max_mod_idx; m >= 0; m--) {
+            int req = orc_number_slots(e, e->cur.bit_rate, m);
+            if (req <= 0) continue;
+            orc_available(e, p, avail);
+            int32_t first;
+            if (orc_candidates(avail, S, req, &first, 1) == 0) continue;
+            if (passes(e, p, first, req, m)) { *bres_out = 0; *bosnr_out = 0; return orc_encode_action(e, k, m, first); }
+        }
+    }
+    *bres_out = 1; *bosnr_out = 0;
+    return orc_reject_action(e);
+}
+
+/* best_modulation_load_balancing (:491-545): ALL modulations outer, routes inner; first free run of >= slots+1 */
+static int orc_policy_best_mod_lb(orc_env *e, int *bres_out, int *bosnr_out) {
+    int S = e->cfg.n_slots;
+    int32_t *avail = e->scratch_avail;
+    int32_t *rs = (int32_t *)malloc(sizeof(int32_t) * (size_t)(S + 1)), *rl = (int32_t *)malloc(sizeof(int32_t) * (size_t)(S + 1));
+    int action = orc_reject_action(e);
+    *bres_out = 0; *bosnr_out = 0;
+    for (int m = e->cfg.n_mods - 1; m >= 0 && action == orc_reject_action(e); m--) {
+        int req = orc_number_slots(e, e->cur.bit_rate, m);
+        for (int k = 0; k < e->cfg.k_paths; k++) {
+            int p = path_of(e, k);
+            if (p < 0) break;
+            orc_available(e, p, avail);
+            int nr = free_runs(avail, S, rs, rl), slot = -1;
+            for (int i = 0; i < nr; i++) if (rl[i] >= req + 1) { slot = rs[i]; break; }
+            if (slot < 0) continue;
+            if (passes(e, p, slot, req, m)) { action = orc_encode_action(e, k, m, slot); break; }
+        }
+    }
+    free(rs); free(rl);
+    return action;
+}
+
+/* heuristic_mscl_simplified (:765-839) / heuristic_mscl_sequential_simplified (:841-921) */
+static int orc_policy_mscl_simplified(orc_env *e, int sequential, int *bres_out, int *bosnr_out) {
+    int bres = 0, bosnr = 0, S = e->cfg.n_slots;
+    int32_t *avail = e->scratch_avail;
+    int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * (size_t)S);
+    int best_action = -1, best_score = -1;
+    for (int k = 0; k < e->cfg.k_paths; k++) {
+        int p = path_of(e, k);
+        if (p < 0) break;
+        if (sequential) { best_action = -1; best_score = -1; }
+        for (int m = e->max_mod_idx; m >= 0; m--) {
+            int req = orc_number_slots(e, e->cur.bit_rate, m);
+            if (req <= 0) continue;
+            orc_available(e, p, avail);
+            int32_t first;
+            if (orc_candidates(avail, S, req, &first, 1) == 0) { bres = 1; continue; }
+            if (passes(e, p, first, req, m)) {
+                memcpy(tmp, avail, sizeof(int32_t) * (size_t)S);
+                for (int j = first; j < first + req && j < S; j++) tmp[j] = 0;
+                int score = largest_free_run(tmp, S);
+                if (score > best_score) { best_score = score; best_action = orc_encode_action(e, k, m, first); }
+            } else bosnr = 1;
+        }
+        if (sequential && best_action >= 0) break;
+    }
+    free(tmp);
+    if (best_action >= 0) { *bres_out = 0; *bosnr_out = 0; return best_action; }
+    *bres_out = bres; *bosnr_out = bosnr;
+    return orc_reject_action(e);
+}
+
+/* heuristic_psr (:1019-1119), default coefficients: the route cost never excludes a route (best_cost stays infinite until
+ * the search ends), so: first route, best modulation, lowest start - ALL starts of a modulation are tried - that passes */
+static int orc_policy_psr(orc_env *e, int *bres_out, int *bosnr_out) {
+    int S = e->cfg.n_slots;
+    int32_t *avail = e->scratch_avail;
+    int32_t *starts = (int32_t *)malloc(sizeof(int32_t) * (size_t)(S + 1));
+    int action = orc_reject_action(e), found = 0;
+    for (int k = 0; k < e->cfg.k_paths && !found; k++) {
+        int p = path_of(e, k);
+        if (p < 0) break;
+        for (int m = e->max_mod_idx; m >= 0 && !found; m--) {
+            int req = orc_number_slots(e, e->cur.bit_rate, m);
+            if (req <= 0) continue;
+            orc_available(e, p, avail);
+            int cnt = orc_candidates(avail, S, req, starts, S + 1);
+            for (int i = 0; i < cnt; i++)
+                if (passes(e, p, starts[i], req, m)) { action = orc_encode_action(e, k, m, starts[i]); found = 1; break; }
+        }
+    }
+    free(starts);
+    *bres_out = found ? 0 : 1; *bosnr_out = 0;
+    return action;
+}
+
+/* heuristic_exact_fit (:1121-1227): first free run of exactly the needed length, else the smallest that is long enough */
+static int orc_policy_exact_fit(orc_env *e, int *bres_out, int *bosnr_out) {
+    int bres = 0, bosnr = 0, S = e->cfg.n_slots;
+    int32_t *avail = e->scratch_avail;
+    int32_t *rs = (int32_t *)malloc(sizeof(int32_t) * (size_t)(S + 1)), *rl = (int32_t *)malloc(sizeof(int32_t) * (size_t)(S + 1));
+    int action = -1;
+    for (int k = 0; k < e->cfg.k_paths && action < 0; k++) {
+        int p = path_of(e, k);
+        if (p < 0) break;
+        for (int m = e->max_mod_idx; m >= 0; m--) {
+            int req = orc_number_slots(e, e->cur.bit_rate, m);
+            if (req <= 0) continue;
+            orc_available(e, p, avail);
+            int nr = free_runs(avail, S, rs, rl), slot = -1;
+            if (nr == 0) { bres = 1; continue; }
+            for (int i = 0; i < nr; i++) if (rl[i] == req) { slot = rs[i]; break; }
+            if (slot < 0) {
+                int best = 0x7fffffff;
+                for (int i = 0; i < nr; i++) if (rl[i] >= req && rl[i] < best) { best = rl[i]; slot = rs[i]; }
+                if (slot < 0) { bres = 1; continue; }
+            }
+            if (passes(e, p, slot, req, m)) { action = orc_encode_action(e, k, m, slot); break; }
+            bosnr = 1;
+        }
+    }
+    free(rs); free(rl);
+    if (action >= 0) { *bres_out = 0; *bosnr_out = 0; return action; }
+    if (bosnr) bres = 0;
+    *bres_out = bres; *bosnr_out = bosnr;
+    return orc_reject_action(e);
+}
+
 int orc_policy(orc_env *e, int policy, int *bres, int *bosnr) {
     if (policy == ONGYM_POLICY_LOAD_BALANCING) return orc_policy_load_balancing(e, bres, bosnr);
     if (policy == ONGYM_POLICY_HIGHEST_SNR) return orc_policy_highest_snr(e, bres, bosnr);
+    if (policy == ONGYM_POLICY_LOWEST_SPECTRUM) return orc_policy_lowest_spectrum(e, bres, bosnr);
+    if (policy == ONGYM_POLICY_LB_FIRST_FIT) return orc_policy_lb_first_fit(e, bres, bosnr);
+    if (policy == ONGYM_POLICY_BEST_MOD_LB) return orc_policy_best_mod_lb(e, bres, bosnr);
+    if (policy == ONGYM_POLICY_MSCL_SIMPLIFIED) return orc_policy_mscl_simplified(e, 0, bres, bosnr);
+    if (policy == ONGYM_POLICY_MSCL_SEQUENTIAL) return orc_policy_mscl_simplified(e, 1, bres, bosnr);
+    if (policy == ONGYM_POLICY_PSR) return orc_policy_psr(e, bres, bosnr);
+    if (policy == ONGYM_POLICY_EXACT_FIT) return orc_policy_exact_fit(e, bres, bosnr);
     return orc_policy_first_fit(e, bres, bosnr);
 }
 

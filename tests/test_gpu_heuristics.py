@@ -1,5 +1,5 @@
-"""Every policy of the reference's heuristics module, run through the plugin API on the device-backed compatibility env
-and compared, decision by decision, with what the reference's own function returned on the same network state
+"""Every policy of the reference's heuristics module — the version fused on device AND the one written against the plugin
+API — on the device-backed compatibility env, compared, decision by decision, with what the reference's own function returned on the same network state
 (tests/golden/dec_*.npz, written by make_golden.py::run_decisions from the compiled reference).
 
 A fixture row = one env.step(): `st_action` is what was applied (the driver's decision, or a forced reject after the env
@@ -19,11 +19,16 @@ TOPO_FILE = {"nsfnet": "nsfnet_chen.txt", "ring4": "ring_4.txt", "cost239": "cos
 
 
 def policy(name):
+    """Every implementation of a policy: the public name (fused on device where one exists) and the plugin-API body."""
     if name == "psr_c":
-        return lambda env: H.heuristic_psr(env, variant="C")
+        return [lambda env: H.heuristic_psr(env, variant="C"), lambda env: H.heuristic_psr_plugin(env, variant="C")]
     if name == "psr_o":
-        return lambda env: H.heuristic_psr(env, variant="O", coef_dist=0.7, coef_slots=1.3)
-    return getattr(H, name)
+        return [lambda env: H.heuristic_psr(env, variant="O", coef_dist=0.7, coef_slots=1.3),
+                lambda env: H.heuristic_psr_plugin(env, variant="O", coef_dist=0.7, coef_slots=1.3)]
+    fns = [getattr(H, name)]
+    if hasattr(H, name + "_plugin"):
+        fns.append(getattr(H, name + "_plugin"))
+    return fns
 
 
 def replay(tag):
@@ -49,10 +54,11 @@ def replay(tag):
         cur = sim.current_service
         if row >= first:
             for n in names:
-                got = fns[n](env)
                 want = d["dec_" + n][row - first]
-                if (int(got[0]), int(bool(got[1])), int(bool(got[2]))) != tuple(int(x) for x in want):
-                    mismatches[n].append((row, got, want.tolist()))
+                for which, fn in enumerate(fns[n]):
+                    got = fn(env)
+                    if (int(got[0]), int(bool(got[1])), int(bool(got[2]))) != tuple(int(x) for x in want):
+                        mismatches[n].append((row, which, got, want.tolist()))
         if d["st_retry"][row] == 2:                 # the reference raised the QoT ValueError (qrmsa.pyx:925-929)
             with pytest.raises(ValueError, match="is not enough for service"):
                 env.step(int(d["st_action"][row]))

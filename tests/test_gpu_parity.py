@@ -538,7 +538,7 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_device():
     with pytest.raises(OngymError, match="path id out of range"):
         env.available_slots(0, P)
     with pytest.raises(OngymError, match="unknown policy"):
-        env.step_policy(1, policy=7)
+        env.step_policy(1, policy=99)
     with pytest.raises(OngymError, match="nsteps"):
         env.step_policy(0)
     moves, total = env.moves(0)                       # defragmentation is off: empty, not an error
@@ -552,3 +552,33 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_device():
                             bit_rate_selection="discrete", bit_rates=(10, 40), **kw)
     with pytest.raises(OngymError, match="n_defrag_services"):
         make_env(meta, defragmentation=True, n_defrag_services=-1)
+
+
+@pytest.mark.parametrize("pid", [3, 4, 5, 6, 7, 8, 9])
+def test_misc_fused_policies_vs_oracle_random_traffic(pid):
+    """policy ids 3..9 (lowest spectrum, LB first fit, best-modulation LB, simplified / sequential MSCL, PSR, exact fit)
+    driving whole batched episodes against the oracle's restatements (which tests/test_oracle_golden.py pins to
+    decisions captured from the reference).  Exact fit exercises the occupied-slots penalty inside the fused loop."""
+    B, steps = 10, 520
+    loads = np.linspace(350, 800, B)
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=256, batch=B, capacity=1024, episode_length=400,
+              auto_reset=True, load=500, bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), replica_load=loads)
+    holder = nat.ConfigHolder(golden_tables("nsfnet"), **kw)
+    env = BatchedQRMSAEnv(tables=golden_tables("nsfnet"), modulations=jocn_modulations(), batch_size=B,
+                          num_spectrum_resources=256, capacity=1024, episode_length=400, auto_reset=True, load=500,
+                          bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), replica_load=loads)
+    env.seed(5); env.reset()
+    got = env.step_policy(steps, policy=pid)
+    st = env.stats()
+    rejected = retried = 0
+    for r in range(B):
+        o = OracleEnv(holder, replica=r)
+        o.seed(5); o.reset()
+        want = o.run_policy(pid, steps)
+        assert_records_equal(got[:, r], want, f"policy {pid} replica {r}")
+        np.testing.assert_array_equal(env.grid(r), o.grid())
+        assert st[r]["services_accepted"] == o.stats()["services_accepted"]
+        rejected += int((want["accepted"] == 0).sum()); retried += int(want["retry"].sum())
+    assert rejected > 5
+    if pid == 9:
+        assert retried > 50

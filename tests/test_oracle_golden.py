@@ -238,3 +238,40 @@ def test_defragmentation_trajectory(tag):
     meta, d = load_traj(tag)
     assert meta["defragmentation"] and d["st_drea"].max() > 20
     replay(tag, policy=True, defragmentation=True, n_defrag_services=meta["n_defrag_services"])
+
+
+# ---- the remaining policies (heuristics.py) against decisions captured from the reference -----------------------------
+ORACLE_POLICY = {"shortest_available_path_lowest_spectrum_best_modulation": 3, "heuristic_load_balancing_first_fit": 4,
+                 "best_modulation_load_balancing": 5, "heuristic_mscl_simplified": 6,
+                 "heuristic_mscl_sequential_simplified": 7, "psr_c": 8, "heuristic_exact_fit": 9}
+
+
+@pytest.mark.parametrize("tag", ["dec_nsfnet320_a", "dec_nsfnet320_b", "dec_nsfnet320_c", "dec_cost239_d"])
+def test_remaining_policies_decide_like_the_reference(tag):
+    """tests/golden/dec_*.npz: at every step the reference's own heuristic functions were evaluated on the same state;
+    the oracle's restatements must return the same (action, blocked_resources, blocked_osnr)."""
+    meta, d = load_traj(tag)
+    over = dict(meta, mean_holding=10800.0, frequency_start=3e8 / 1565e-9, slot_bw=12.5e9)
+    env = OracleEnv(holder_for(over))
+    env.set_trace(traj_requests(d))
+    for _ in range(meta["initial_resets"]):
+        env.reset()
+    names = [n for n in [meta["driver"]] + list(meta["observers"]) if n in ORACLE_POLICY]
+    rows = len(d["st_action"])
+    first = rows - len(d["dec_" + meta["driver"]])
+    checked = 0
+    for row in range(rows):
+        if row >= first:
+            for n in names:
+                got = env.policy(ORACLE_POLICY[n])
+                want = d["dec_" + n][row - first]
+                assert (got[0], int(got[1]), int(got[2])) == tuple(int(x) for x in want), (n, row)
+                checked += 1
+        rc, r = env.step(int(d["st_action"][row]))
+        if d["st_retry"][row] == 2:
+            assert rc != 0 and (r["flags"] & 4)          # ONGYM_F_QOT_ERROR: the reference raised its ValueError
+        else:
+            assert rc == 0 and r["retry"] == d["st_retry"][row] and r["reward"] == d["st_reward"][row], row
+            if not r["retry"]:
+                assert r["accepted"] == d["st_accepted"][row], row
+    assert checked == len(names) * len(d["dec_" + meta["driver"]]) >= 750
