@@ -68,6 +68,7 @@ struct Params {
     double f0, slot_bw, channel_width, mean_holding;
     float mean_holding_f, pad_f;    // (float)mean_holding
     const int32_t *nreq_tab;        // [n_bit_rates*8] slots needed per (discrete bit rate, modulation)
+    const double *req_coef;         // [n_bit_rates*8][2] (nli_coef[n], self_asinh[n]) of that slot count (0 if n is not in [1, S])
     double alpha0_cl;               // pi^2 |beta2| / (2 alpha) when alpha is uniform
     // constant tables
     const int32_t *pair_paths;      // [N*N*K]
@@ -108,15 +109,15 @@ struct Params {
 
 // ---------------------------------------------------------------------------------------------------------------
 // LDS carve-up (dynamic shared memory), 8-byte aligned pieces first
-//   occ u64[E*W] | lw1 f64[E] | lw2 f64[E] | lcl f64[E] | lsc f64[E] | DevEnv | sa u32[C] | sb u32[C] | sr f32[C] |
-//   lim f64[8] | rp f64[2] | phi f64[8] | nreq i32[8] | list u16[C] |
+//   occ u64[E*W] | lw f64[2E] (w1, w2 interleaved) | lcl f64[E] | lsc f64[E] | DevEnv | sa u32[C] | sb u32[C] | sr f32[C] |
+//   lim f64[8] | rp f64[2] | phi f64[8] | nlic f64[8] | selfa f64[8] | nreq i32[8] | list u16[C] |
 //   (lim0 f64[8] when measure_disruptions or defragmentation) | (so f64[C] | sq u32[C] when defragmentation)
 // (DevEnv = its first kEnvHotBytes)
 // ---------------------------------------------------------------------------------------------------------------
 __host__ __device__ inline size_t lds_bytes(int n_links, int row_words, int capacity, int uniform_alpha,
                                             int measure_disruptions, int defragmentation) {
     size_t b = (size_t)n_links * row_words * 8 + (size_t)n_links * (uniform_alpha ? 16 : 32) + kEnvHotBytes;
-    b += (size_t)capacity * 12 + 64 + 16 + 64 + 32 + (size_t)capacity * 2;
+    b += (size_t)capacity * 12 + 64 + 16 + 64 + 128 + 32 + (size_t)capacity * 2;
     b += (measure_disruptions || defragmentation) ? 64 : 0;
     b += defragmentation ? (size_t)capacity * 12 : 0;
     return (b + 15) & ~(size_t)15;
@@ -127,15 +128,17 @@ __host__ __device__ inline size_t lds_bytes(const Params &P) {
 }
 
 #ifdef ONGYM_STAMPS
-#define ONGYM_NSTAMPS 10
+#define ONGYM_NSTAMPS 16
 #define STAMP(c, idx)                                                         \
     do {                                                                      \
         unsigned long long _t = __builtin_amdgcn_s_memtime();                 \
         (c).stamp_acc[idx] += _t - (c).stamp_last;                            \
         (c).stamp_last = _t;                                                  \
     } while (0)
+#define STAMPW(c, idx) do { __builtin_amdgcn_s_waitcnt(0); STAMP(c, idx); } while (0)   /* drain, then stamp */
 #else
 #define STAMP(c, idx) do { } while (0)
+#define STAMPW(c, idx) do { } while (0)
 #endif
 
 // extra LDS of the kernels that evaluate EVERY candidate of a path (observation, highest-SNR policy)
@@ -150,7 +153,7 @@ struct Ctx {
     int lane;
     int replica;
     uint64_t *occ;
-    double *lw1, *lw2, *lcl, *lsc;
+    double *lw, *lcl, *lsc;   // lw[2l] = w1_l, lw[2l+1] = w2_l (interleaved: one ds_read2_b64 per link)
     DevEnv *e;
     uint32_t *sa, *sb;
     float *sr;
@@ -162,6 +165,8 @@ struct Ctx {
     double *so;        // LDS [C] Service.OSNR per record        } defragmentation only
     uint32_t *sq;      // LDS [C] Service.service_id per record  }
     double *phi;       // LDS [8] Phi_mod * 5/3 per modulation
+    double *nlic;      // LDS [8] nli_coef[nreq[m]] * launch_power^2 of the CURRENT request } refreshed with nreq: the policy
+    double *selfa;     // LDS [8] self_asinh[nreq[m]]                                        } reads them at LDS latency
     uint16_t *list;
     double node_cum_reg;   // node_cum[lane] (+inf beyond n_nodes) when n_nodes <= 64
     double br_cum_reg;     // bit_rate_cum[lane] (+inf beyond n_bit_rates)
@@ -170,6 +175,7 @@ struct Ctx {
     // round trips overlap the departures scan (id < 0: no such path)
     int pre_id, pre_hops, pre_mylink;
     uint64_t pre_m0, pre_m1;
+    double pre_ase, pre_w1;
     int active;        // running services (wave-uniform, mirrored to e->st.active at store time)
     int lane_terms;    // per-lane interferer-link term counter (reduced once per launch)
     // sum of Service.OSNR = -10 log10(acc) over accepted services, kept as -10 log10 of a running PRODUCT of the acc's
@@ -185,10 +191,9 @@ struct Ctx {
 __device__ __forceinline__ void ctx_bind(Ctx &c, unsigned char *smem) {
     const Params &P = c.P;
     c.occ = reinterpret_cast<uint64_t *>(smem);
-    c.lw1 = reinterpret_cast<double *>(c.occ + (size_t)P.n_links * P.row_words);
-    c.lw2 = c.lw1 + P.n_links;
+    c.lw = reinterpret_cast<double *>(c.occ + (size_t)P.n_links * P.row_words);
     // the per-link alpha tables exist only when the attenuation is not uniform
-    c.lcl = c.lw2 + P.n_links;
+    c.lcl = c.lw + 2 * P.n_links;
     c.lsc = c.lcl + (P.uniform_alpha ? 0 : P.n_links);
     c.e = reinterpret_cast<DevEnv *>(c.lsc + (P.uniform_alpha ? 0 : P.n_links));
     c.sa = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(c.e) + kEnvHotBytes);
@@ -197,7 +202,9 @@ __device__ __forceinline__ void ctx_bind(Ctx &c, unsigned char *smem) {
     c.lim = reinterpret_cast<double *>(c.sr + P.capacity);   // capacity is a multiple of 64 -> 8-byte aligned
     c.rp = c.lim + 8;
     c.phi = c.rp + 2;
-    c.nreq = reinterpret_cast<int *>(c.phi + 8);
+    c.nlic = c.phi + 8;
+    c.selfa = c.nlic + 8;
+    c.nreq = reinterpret_cast<int *>(c.selfa + 8);
     c.list = reinterpret_cast<uint16_t *>(c.nreq + 8);
     c.lim0 = reinterpret_cast<double *>(c.list + P.capacity);   // capacity % 64 == 0 -> 8-byte aligned; only if enabled
     c.so = c.lim0 + 8;                                          // only with defragmentation
@@ -335,6 +342,7 @@ struct PathRef {
     int id, hops;
     int mylink;          // link index of hop `lane` (undefined for lane >= hops)
     uint64_t m0, m1;     // link mask
+    double ase, w1;      // path_ase[id], path_w1[id] (wave-uniform)
 };
 
 __device__ __forceinline__ void prefetch_first_path(Ctx &c, int src, int dst) {
@@ -346,6 +354,8 @@ __device__ __forceinline__ void prefetch_first_path(Ctx &c, int src, int dst) {
         c.pre_mylink = (c.lane < c.pre_hops) ? G(P.path_links)[path * P.max_hops + c.lane] : 0;
         c.pre_m0 = G(P.path_mask)[2 * path];
         c.pre_m1 = G(P.path_mask)[2 * path + 1];
+        c.pre_ase = G(P.path_ase)[path];
+        c.pre_w1 = G(P.path_w1)[path];
     }
 }
 
@@ -357,6 +367,8 @@ __device__ __forceinline__ PathRef load_path(const Ctx &c, int path) {
     r.mylink = (c.lane < r.hops) ? G(P.path_links)[path * P.max_hops + c.lane] : 0;
     r.m0 = G(P.path_mask)[2 * path];
     r.m1 = G(P.path_mask)[2 * path + 1];
+    r.ase = G(P.path_ase)[path];
+    r.w1 = G(P.path_w1)[path];
     return r;
 }
 
@@ -438,19 +450,46 @@ struct GnLin {          // noise-to-signal ratios in the linear domain (wave-uni
 // pass 2: 1/SNR_ase and 1/SNR_nli of a candidate lightpath (path, slot s, n slots) against the compacted interferers.
 // Span-hoisted: every span of a link is identical (topology.pyx:288-299), so the per-span sums of core/osnr.pyx:50-135
 // collapse to per-link weights w1 = nspans*l_eff, w2 = nspans*l_eff*l_eff/(L*1e3) (quirk Q11).
+struct GnCoef {         // the candidate's slot-count dependent factors (wave-uniform)
+    double nlic;        // nli_coef[n] * launch_power^2
+    double selfa;       // self_asinh[n] (uniform attenuation)
+};
+__device__ __forceinline__ GnCoef coef_for_slots(const Ctx &c, int n) {      // table loads (queries, arbitrary n)
+    GnCoef k;
+    k.nlic = G(c.P.nli_coef)[n] * c.rp[1];
+    k.selfa = G(c.P.self_asinh)[n];
+    return k;
+}
+__device__ __forceinline__ GnCoef coef_for_mod(const Ctx &c, int m) {        // the current request's, from LDS
+    GnCoef k;
+    k.nlic = c.nlic[m];
+    k.selfa = c.selfa[m];
+    return k;
+}
+// refresh nlic / selfa after nreq changed (lane m -> modulation m); n outside [1, S] never reaches the GN model
+__device__ __forceinline__ void set_request_coefs(Ctx &c, int n, double lp2) {
+    const Params &P = c.P;
+    if (c.lane < P.n_mods) {
+        const bool ok = n >= 1 && n <= P.n_slots;
+        c.nlic[c.lane] = ok ? G(P.nli_coef)[n] * lp2 : 0.0;
+        c.selfa[c.lane] = ok ? G(P.self_asinh)[n] : 0.0;
+    }
+}
+
 template <bool UNIFORM_ALPHA, bool R32>
-__device__ __forceinline__ GnLin gn_eval(Ctx &c, const PathRef &p, int L, int s, int n) {
+__device__ __forceinline__ GnLin gn_eval(Ctx &c, const PathRef &p, int L, int s, int n, const GnCoef &kf) {
     const Params &P = c.P;
     const double bw = P.slot_bw * n;
     const int c2 = 2 * s + n;  // candidate centre in half-slots
     double part = 0.0;
     // self-channel term asinh(pi^2 |b2| B^2 / (4 alpha)) per link (core/osnr.pyx:58-61)
     if (UNIFORM_ALPHA) {
-        if (c.lane == 0) part = G(P.path_w1)[p.id] * G(P.self_asinh)[n];
+        if (c.lane == 0) part = p.w1 * kf.selfa;
     } else {
-        if (c.lane < p.hops) part = c.lw1[p.mylink] * asinh(c.lsc[p.mylink] * (bw * bw));
+        if (c.lane < p.hops) part = c.lw[2 * (p.mylink)] * asinh(c.lsc[p.mylink] * (bw * bw));
     }
     int terms = 0;
+    STAMPW(c, 10);
     for (int j = c.lane; j < L; j += kWave) {
         int idx = c.list[j];
         uint32_t a = c.sa[idx], b = c.sb[idx];
@@ -459,12 +498,14 @@ __device__ __forceinline__ GnLin gn_eval(Ctx &c, const PathRef &p, int L, int s,
         uint64_t m0, m1;
         if (R32) { m0 = a & (uint32_t)p.m0; m1 = 0; }
         else { int pk = a & 0xFFFF; m0 = G(P.path_mask)[2 * pk] & p.m0; m1 = G(P.path_mask)[2 * pk + 1] & p.m1; }
+        STAMPW(c, 11);
         if (UNIFORM_ALPHA) {
             double A, corr;
             if (nk <= P.tab_nmax) {   // (asinh difference, Bk/|df|) depend on two small integers only: one 16-byte gather
                 const auto *t = G(reinterpret_cast<const double *>(P.pair_tab)) + 2 * ((nk - 1) * P.tab_stride + adi);
                 A = t[0];
                 corr = c.phi[mk] * t[1];
+                STAMPW(c, 12);
             } else {
                 double bk = P.slot_bw * nk, adf = (0.5 * P.slot_bw) * (double)adi, ck = P.alpha0_cl * bk;
                 A = asinh_diff(ck * (adf + 0.5 * bk), ck * (adf - 0.5 * bk));   // adf > bk/2: allocations never overlap
@@ -474,11 +515,11 @@ __device__ __forceinline__ GnLin gn_eval(Ctx &c, const PathRef &p, int L, int s,
             if (R32) {
                 uint32_t m = (uint32_t)m0;
                 terms += __popc(m);
-                while (m) { int l = __ffs(m) - 1; m &= m - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
+                while (m) { int l = __ffs(m) - 1; m &= m - 1; w1 += c.lw[2 * (l)]; w2 += c.lw[2 * (l) + 1]; }
             } else {
                 terms += __popcll((unsigned long long)m0) + __popcll((unsigned long long)m1);
-                while (m0) { int l = __ffsll((unsigned long long)m0) - 1; m0 &= m0 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
-                while (m1) { int l = 64 + __ffsll((unsigned long long)m1) - 1; m1 &= m1 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
+                while (m0) { int l = __ffsll((unsigned long long)m0) - 1; m0 &= m0 - 1; w1 += c.lw[2 * (l)]; w2 += c.lw[2 * (l) + 1]; }
+                while (m1) { int l = 64 + __ffsll((unsigned long long)m1) - 1; m1 &= m1 - 1; w1 += c.lw[2 * (l)]; w2 += c.lw[2 * (l) + 1]; }
             }
             part += A * w1 - corr * w2;
         } else {
@@ -490,20 +531,27 @@ __device__ __forceinline__ GnLin gn_eval(Ctx &c, const PathRef &p, int L, int s,
                 if (m0) { l = __ffsll((unsigned long long)m0) - 1; m0 &= m0 - 1; }
                 else { l = 64 + __ffsll((unsigned long long)m1) - 1; m1 &= m1 - 1; }
                 double ck = c.lcl[l] * bk;
-                part += asinh_diff(ck * hi, ck * lo) * c.lw1[l] - corr * c.lw2[l];
+                part += asinh_diff(ck * hi, ck * lo) * c.lw[2 * (l)] - corr * c.lw[2 * (l) + 1];
             }
         }
     }
     c.lane_terms += terms;
     c.gn_evals++;
+    STAMPW(c, 13);
     double total = wave_sum(part);
+    STAMPW(c, 14);
     // P_nli/P = (P/B)^3 * 8/(27 pi |b2|) * gamma^2 * B / P * sum = nli_coef[n] * P^2 * sum   (core/osnr.pyx:109-116,135)
     // P_ase/P = B * h * fc * sum_l n_l (exp(2 a L) - 1) NF / P                                 (core/osnr.pyx:119-125,134)
     double fc = P.f0 + (P.slot_bw * s) + (P.slot_bw * (n / 2.0));  // envs/qrmsa.pyx:901-905
     GnLin g;
-    g.nli = (G(P.nli_coef)[n] * c.rp[1]) * total;
-    g.ase = (bw * fc * G(P.path_ase)[p.id]) * c.rp[0];
+    g.nli = kf.nlic * total;
+    g.ase = (bw * fc * p.ase) * c.rp[0];
+    STAMPW(c, 15);
     return g;
+}
+template <bool UNIFORM_ALPHA, bool R32>
+__device__ __forceinline__ GnLin gn_eval(Ctx &c, const PathRef &p, int L, int s, int n) {
+    return gn_eval<UNIFORM_ALPHA, R32>(c, p, L, s, n, coef_for_slots(c, n));
 }
 
 __device__ __forceinline__ void gn_to_db(const GnLin &g, double out[3]) {   // core/osnr.pyx:138-140
@@ -546,7 +594,7 @@ __device__ __forceinline__ void policy_first_fit(Ctx &c, int src, int dst, doubl
         int path = k == 0 ? c.pre_id : G(P.pair_paths)[(src * P.n_nodes + dst) * P.k_paths + k];
         if (path < 0) break;
         PathRef p;
-        if (k == 0) { p.id = path; p.hops = c.pre_hops; p.mylink = c.pre_mylink; p.m0 = c.pre_m0; p.m1 = c.pre_m1; }
+        if (k == 0) { p.id = path; p.hops = c.pre_hops; p.mylink = c.pre_mylink; p.m0 = c.pre_m0; p.m1 = c.pre_m1; p.ase = c.pre_ase; p.w1 = c.pre_w1; }
         else p = load_path(c, path);
         c.paths_tried++; c.path_hops += p.hops;
         const uint64_t free_ext = path_free_ext(c, p);
@@ -568,12 +616,12 @@ __device__ __forceinline__ void policy_first_fit(Ctx &c, int src, int dst, doubl
                 // gn_eval, same 1e-9 guard band as qot_ok).
                 double bw = P.slot_bw * n;
                 double fc = P.f0 + (P.slot_bw * first) + (P.slot_bw * (n / 2.0));
-                double lb = (bw * fc * G(P.path_ase)[path]) * c.rp[0];
-                if (UNIFORM_ALPHA) lb += (G(P.nli_coef)[n] * c.rp[1]) * (G(P.path_w1)[path] * G(P.self_asinh)[n]);
+                double lb = (bw * fc * p.ase) * c.rp[0];
+                if (UNIFORM_ALPHA) lb += c.nlic[m] * (p.w1 * c.selfa[m]);
                 if (uniform_i32(lb >= c.lim[m] * (1.0 + 1e-9))) { bosnr = 1; bres = 0; c.gn_skips++; continue; }
             }
             if (L < 0) { L = gn_build_list<R32>(c, p.m0, p.m1); STAMP(c, 3); }
-            GnLin g = gn_eval<UNIFORM_ALPHA, R32>(c, p, L, first, n);
+            GnLin g = gn_eval<UNIFORM_ALPHA, R32>(c, p, L, first, n, coef_for_mod(c, m));
             int ok = qot_ok(c, g, m, margin);
             STAMP(c, 4);
             if (ok) {
@@ -608,7 +656,7 @@ __device__ __forceinline__ void policy_load_balancing(Ctx &c, int src, int dst, 
         int path = k == 0 ? c.pre_id : G(P.pair_paths)[(src * P.n_nodes + dst) * P.k_paths + k];
         if (path < 0) break;
         PathRef p;
-        if (k == 0) { p.id = path; p.hops = c.pre_hops; p.mylink = c.pre_mylink; p.m0 = c.pre_m0; p.m1 = c.pre_m1; }
+        if (k == 0) { p.id = path; p.hops = c.pre_hops; p.mylink = c.pre_mylink; p.m0 = c.pre_m0; p.m1 = c.pre_m1; p.ase = c.pre_ase; p.w1 = c.pre_w1; }
         else p = load_path(c, path);
         c.paths_tried++; c.path_hops += p.hops;
         const uint64_t free_ext = path_free_ext(c, p);
@@ -632,12 +680,12 @@ __device__ __forceinline__ void policy_load_balancing(Ctx &c, int src, int dst, 
             if (P.ase_shortcut) {   // exact lower bound, see policy_first_fit
                 double bw = P.slot_bw * n;
                 double fc = P.f0 + (P.slot_bw * first) + (P.slot_bw * (n / 2.0));
-                double lb = (bw * fc * G(P.path_ase)[path]) * c.rp[0];
-                if (UNIFORM_ALPHA) lb += (G(P.nli_coef)[n] * c.rp[1]) * (G(P.path_w1)[path] * G(P.self_asinh)[n]);
+                double lb = (bw * fc * p.ase) * c.rp[0];
+                if (UNIFORM_ALPHA) lb += c.nlic[m] * (p.w1 * c.selfa[m]);
                 if (uniform_i32(lb >= c.lim[m] * (1.0 + 1e-9))) { any_osnr = 1; c.gn_skips++; continue; }
             }
             if (L < 0) L = gn_build_list<R32>(c, p.m0, p.m1);
-            GnLin g = gn_eval<UNIFORM_ALPHA, R32>(c, p, L, first, n);
+            GnLin g = gn_eval<UNIFORM_ALPHA, R32>(c, p, L, first, n, coef_for_mod(c, m));
             if (qot_ok(c, g, m, margin)) {
                 lowest_load = current_load;
                 ch.action = k * M * S + (max_mod - m) * S + first;
@@ -682,7 +730,7 @@ __device__ __forceinline__ int evaluate_action(Ctx &c, int src, int dst, double 
     uint64_t w = readlane_u64(ok_starts, uniform_i32(slot >> 6));
     if (!((w >> (slot & 63)) & 1ull)) return 2;
     int L = gn_build_list<R32>(c, p.m0, p.m1);
-    GnLin g = gn_eval<UNIFORM_ALPHA, R32>(c, p, L, slot, n);
+    GnLin g = gn_eval<UNIFORM_ALPHA, R32>(c, p, L, slot, n, coef_for_mod(c, m));
     ch.g.ase = uniform_f64(g.ase); ch.g.nli = uniform_f64(g.nli);
     return qot_ok(c, g, m, margin) ? 0 : 3;
 }
@@ -967,9 +1015,23 @@ __device__ __forceinline__ void draw_next(Ctx &c) {
     }
     // slots needed per modulation: get_number_slots (envs/qrmsa.pyx:1198-1205), lane m -> nreq[m]
     prefetch_first_path(c, src, dst);
-    if (c.lane < P.n_mods)
-        c.nreq[c.lane] = bi >= 0 ? G(P.nreq_tab)[bi * kMaxMods + c.lane]
-                                 : (int)ceil((double)br / ((double)P.mod_se[c.lane] * P.channel_width));
+    if (bi >= 0) {   // discrete bit rates: slot count and its GN factors by (bit rate, modulation), independent loads
+        if (c.lane < P.n_mods) {
+            const int at_ = bi * kMaxMods + c.lane;
+            const int nr = G(P.nreq_tab)[at_];
+            const double k0 = G(P.req_coef)[2 * at_], k1 = G(P.req_coef)[2 * at_ + 1];
+            c.nreq[c.lane] = nr;
+            c.nlic[c.lane] = k0 * c.rp[1];
+            c.selfa[c.lane] = k1;
+        }
+    } else {
+        int nr = 0;
+        if (c.lane < P.n_mods) {
+            nr = (int)ceil((double)br / ((double)P.mod_se[c.lane] * P.channel_width));
+            c.nreq[c.lane] = nr;
+        }
+        set_request_coefs(c, nr, c.rp[1]);
+    }
     if (c.lane == 0) {
         e->req_index++;
         e->st.current_time = (double)at;
@@ -1073,8 +1135,8 @@ __device__ __forceinline__ GnLin gn_service_acc(Ctx &c, int iy, int py, int sy, 
             corr = c.phi[mk] * (bk / adf);
         }
         double w1 = 0.0, w2 = 0.0;
-        while (m0) { int l = __ffsll((unsigned long long)m0) - 1; m0 &= m0 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
-        while (m1) { int l = 64 + __ffsll((unsigned long long)m1) - 1; m1 &= m1 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
+        while (m0) { int l = __ffsll((unsigned long long)m0) - 1; m0 &= m0 - 1; w1 += c.lw[2 * (l)]; w2 += c.lw[2 * (l) + 1]; }
+        while (m1) { int l = 64 + __ffsll((unsigned long long)m1) - 1; m1 &= m1 - 1; w1 += c.lw[2 * (l)]; w2 += c.lw[2 * (l) + 1]; }
         part += A * w1 - corr * w2;
     }
     if (c.lane == 0) part += G(P.path_w1)[py] * G(P.self_asinh)[ny];
@@ -1438,8 +1500,8 @@ __device__ __forceinline__ void build_field(Ctx &c, const PathRef &p, uint64_t f
             if (R32) { m0 = a & (uint32_t)p.m0; m1 = 0; }
             else { int pk = a & 0xFFFF; m0 = G(P.path_mask)[2 * pk] & p.m0; m1 = G(P.path_mask)[2 * pk + 1] & p.m1; }
             double w2 = 0.0;
-            while (m0) { int l = __ffsll((unsigned long long)m0) - 1; m0 &= m0 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
-            while (m1) { int l = 64 + __ffsll((unsigned long long)m1) - 1; m1 &= m1 - 1; w1 += c.lw1[l]; w2 += c.lw2[l]; }
+            while (m0) { int l = __ffsll((unsigned long long)m0) - 1; m0 &= m0 - 1; w1 += c.lw[2 * (l)]; w2 += c.lw[2 * (l) + 1]; }
+            while (m1) { int l = 64 + __ffsll((unsigned long long)m1) - 1; m1 &= m1 - 1; w1 += c.lw[2 * (l)]; w2 += c.lw[2 * (l) + 1]; }
             pw2 = c.phi[rec_mod<R32>(a, b)] * w2;
         }
         const int tile_n = min(kWave, L - base);
@@ -1633,7 +1695,7 @@ __device__ __forceinline__ void policy_highest_snr(Ctx &c, int src, int dst, dou
         int path = k == 0 ? c.pre_id : G(P.pair_paths)[(src * P.n_nodes + dst) * P.k_paths + k];
         if (path < 0) break;
         PathRef p;
-        if (k == 0) { p.id = path; p.hops = c.pre_hops; p.mylink = c.pre_mylink; p.m0 = c.pre_m0; p.m1 = c.pre_m1; }
+        if (k == 0) { p.id = path; p.hops = c.pre_hops; p.mylink = c.pre_mylink; p.m0 = c.pre_m0; p.m1 = c.pre_m1; p.ase = c.pre_ase; p.w1 = c.pre_w1; }
         else p = load_path(c, path);
         c.paths_tried++; c.path_hops += p.hops;
         const uint64_t free_ext = path_free_ext(c, p);
@@ -1700,7 +1762,7 @@ __device__ __forceinline__ void load_state(Ctx &c) {
     uint64_t *le = reinterpret_cast<uint64_t *>(c.e);
     for (int i = c.lane; i < (int)(kEnvHotBytes / 8); i += kWave) le[i] = ge[i];
     for (int i = c.lane; i < P.n_links; i += kWave) {
-        c.lw1[i] = P.link_w1[i]; c.lw2[i] = P.link_w2[i];
+        c.lw[2 * (i)] = P.link_w1[i]; c.lw[2 * (i) + 1] = P.link_w2[i];
         if (!P.uniform_alpha) { c.lcl[i] = P.link_cl[i]; c.lsc[i] = P.link_selfc[i]; }
     }
     int words = P.n_links * P.row_words;
@@ -1721,8 +1783,14 @@ __device__ __forceinline__ void load_state(Ctx &c) {
     if (c.lane < kMaxMods) c.phi[c.lane] = c.lane < P.n_mods ? P.mod_phi53[c.lane] : 0.0;
     if (c.lane == 0) { c.rp[0] = 1.0 / c.e->launch_power; c.rp[1] = c.e->launch_power * c.e->launch_power; }
     // slots needed by the current request (kept in LDS between requests, recomputed on load)
-    if (c.lane < P.n_mods)
-        c.nreq[c.lane] = (int)ceil((double)c.e->cur_br / ((double)P.mod_se[c.lane] * P.channel_width));
+    {
+        int nr = 0;
+        if (c.lane < P.n_mods) {
+            nr = (int)ceil((double)c.e->cur_br / ((double)P.mod_se[c.lane] * P.channel_width));
+            c.nreq[c.lane] = nr;
+        }
+        set_request_coefs(c, nr, c.e->launch_power * c.e->launch_power);
+    }
     size_t off = (size_t)c.replica * P.capacity;
     for (int i = c.lane; i < c.active; i += kWave) { c.sa[i] = P.svc_a[off + i]; c.sb[i] = P.svc_b[off + i]; c.sr[i] = P.svc_r[off + i]; }
     if (P.defragmentation)

@@ -478,6 +478,15 @@ static int build(ongym_env *env, const ongym_config *c) {
     if ((rc = upload(env, path_w1.data(), path_w1.size(), &P.path_w1))) return rc;
     if ((rc = upload(env, self_asinh.data(), self_asinh.size(), &P.self_asinh))) return rc;
     if ((rc = upload(env, nli_coef.data(), nli_coef.size(), &P.nli_coef))) return rc;
+    {   // (nli_coef[n], self_asinh[n]) of the slot count of every (discrete bit rate, modulation): lets the request draw
+        // fetch them with the SAME index as nreq_tab instead of a second, dependent round trip through n
+        std::vector<double> rc2(nreq_tab.size() * 2, 0.0);
+        for (size_t i = 0; i < nreq_tab.size(); i++) {
+            const int32_t n = nreq_tab[i];
+            if (n >= 1 && n <= c->n_slots) { rc2[2 * i] = nli_coef[(size_t)n]; rc2[2 * i + 1] = self_asinh[(size_t)n]; }
+        }
+        if ((rc = upload(env, rc2.data(), rc2.size(), &P.req_coef))) return rc;
+    }
     if ((rc = upload(env, w1.data(), w1.size(), &P.link_w1))) return rc;
     if ((rc = upload(env, w2.data(), w2.size(), &P.link_w2))) return rc;
     if ((rc = upload(env, cl.data(), cl.size(), &P.link_cl))) return rc;

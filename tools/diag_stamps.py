@@ -19,7 +19,9 @@ import bench  # noqa: E402
 from optical_networking_gym.envs.batched import BatchedQRMSAEnv  # noqa: E402
 
 NAMES = ["0 request+nslots", "1 path load+AND", "2 run_and/first_set", "3 gn_build_list", "4 gn_eval", "5 mark_links",
-         "6 lane0 bookkeeping+draw", "7 release_due", "8 load_state", "9 store_state"]
+         "6 lane0 bookkeeping+draw", "7 release_due", "8 load_state", "9 store_state",
+         "10 gn: self term/setup", "11 gn: list+record LDS", "12 gn: pair-table gather", "13 gn: link-weight loop",
+         "14 gn: wave_sum", "15 gn: tail (coef loads)"]
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=65536)
@@ -40,7 +42,7 @@ env.step_policy(args.steps, record=False)
 env.sync()
 ms = env.last_kernel_ms()
 env.lib.ongym_debug_stamps(env._h, out)
-v = np.array(list(out)[:10], np.float64)
+v = np.array(list(out)[:16], np.float64)
 tot = v.sum()
 print(f"kernel {ms:.2f} ms; {args.batch * args.steps / ms / 1e3:.3e} steps/s (stamped build)")
 for n, x in zip(NAMES, v):
