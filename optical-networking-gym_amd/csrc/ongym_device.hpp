@@ -168,9 +168,6 @@ struct Ctx {
     double *nlic;      // LDS [8] nli_coef[nreq[m]] * launch_power^2 of the CURRENT request } refreshed with nreq: the policy
     double *selfa;     // LDS [8] self_asinh[nreq[m]]                                        } reads them at LDS latency
     uint16_t *list;
-    double node_cum_reg;   // node_cum[lane] (+inf beyond n_nodes) when n_nodes <= 64
-    double br_cum_reg;     // bit_rate_cum[lane] (+inf beyond n_bit_rates)
-    float br_reg;          // bit_rates[lane]
     // first candidate path of the CURRENT request, loaded right after the request was drawn so that the table
     // round trips overlap the departures scan (id < 0: no such path)
     int pre_id, pre_hops, pre_mylink;
@@ -420,19 +417,22 @@ template <bool R32>
 __device__ __forceinline__ int gn_build_list(Ctx &c, uint64_t cm0, uint64_t cm1) {
     const Params &P = c.P;
     int L = 0;
-    for (int base = 0; base < c.active; base += kWave) {
-        int i = base + c.lane;
-        bool ov = false;
-        if (i < c.active) {
-            if (R32) ov = (c.sa[i] & (uint32_t)cm0) != 0;
-            else {
-                int pk = c.sa[i] & 0xFFFF;
-                ov = ((G(P.path_mask)[2 * pk] & cm0) | (G(P.path_mask)[2 * pk + 1] & cm1)) != 0;
-            }
+    // two chunks of 64 records per iteration: both LDS reads (and, in the generic codec, both mask gathers) are in flight
+    // before the first ballot
+    for (int base = 0; base < c.active; base += 2 * kWave) {
+        const int i0 = base + c.lane, i1 = i0 + kWave;
+        const uint32_t a0 = i0 < c.active ? c.sa[i0] : 0u, a1 = i1 < c.active ? c.sa[i1] : 0u;
+        bool ov0 = false, ov1 = false;
+        if (R32) { ov0 = (a0 & (uint32_t)cm0) != 0; ov1 = (a1 & (uint32_t)cm0) != 0; }
+        else {
+            if (i0 < c.active) { const int pk = a0 & 0xFFFF; ov0 = ((G(P.path_mask)[2 * pk] & cm0) | (G(P.path_mask)[2 * pk + 1] & cm1)) != 0; }
+            if (i1 < c.active) { const int pk = a1 & 0xFFFF; ov1 = ((G(P.path_mask)[2 * pk] & cm0) | (G(P.path_mask)[2 * pk + 1] & cm1)) != 0; }
         }
-        uint64_t bal = __ballot(ov);
-        if (ov) c.list[L + __popcll((unsigned long long)(bal & lanes_below(c.lane)))] = (uint16_t)i;
-        L += __popcll((unsigned long long)bal);
+        const uint64_t bal0 = __ballot(ov0), bal1 = __ballot(ov1);
+        const int n0 = __popcll((unsigned long long)bal0);
+        if (ov0) c.list[L + __popcll((unsigned long long)(bal0 & lanes_below(c.lane)))] = (uint16_t)i0;
+        if (ov1) c.list[L + n0 + __popcll((unsigned long long)(bal1 & lanes_below(c.lane)))] = (uint16_t)i1;
+        L += n0 + __popcll((unsigned long long)bal1);
     }
     wave_sync();
     return L;
@@ -973,6 +973,11 @@ __device__ __forceinline__ void draw_next(Ctx &c) {
     if (e->have_request) return;
     float at, ht, br; int src, dst, bi = -1;
     if (P.req_mode == kReqRng) {
+        // traffic tables, one entry per lane (ballot searches below): loaded here rather than kept in registers across the
+        // whole step — they hit L1 and the latency hides behind the hash and the logarithm
+        const double node_cum_reg = (c.lane < P.n_nodes && P.n_nodes <= kWave) ? G(P.node_cum)[c.lane] : INFINITY;
+        const double br_cum_reg = (c.lane < P.n_bit_rates && P.n_bit_rates <= kWave) ? G(P.bit_rate_cum)[c.lane] : INFINITY;
+        const float br_reg = (c.lane < P.n_bit_rates && P.n_bit_rates <= kWave) ? (float)G(P.bit_rates)[c.lane] : 0.f;
         // the five uniforms of this request in lanes 0..4, the two logarithms in lanes 0 and 1
         const uint64_t key = e->rng_key, ctr = e->req_index * ONGYM_DRAWS_PER_REQUEST;
         const double ul = ongym_uniform(key, ctr + (uint64_t)min(c.lane, ONGYM_DRAWS_PER_REQUEST - 1));
@@ -985,20 +990,20 @@ __device__ __forceinline__ void draw_next(Ctx &c) {
         ht = -l1 * P.mean_holding_f;
         const int n = P.n_nodes;
         const bool small = n <= kWave;
-        double total = small ? readlane_f64(c.node_cum_reg, n - 1) : P.node_cum[n - 1];
-        src = cum_search(c, P.node_cum, c.node_cum_reg, n, u2 * total);
-        double hi_s = small ? readlane_f64(c.node_cum_reg, src) : P.node_cum[src];
-        double lo_s = src > 0 ? (small ? readlane_f64(c.node_cum_reg, src - 1) : P.node_cum[src - 1]) : 0.0;
+        double total = small ? readlane_f64(node_cum_reg, n - 1) : P.node_cum[n - 1];
+        src = cum_search(c, P.node_cum, node_cum_reg, n, u2 * total);
+        double hi_s = small ? readlane_f64(node_cum_reg, src) : P.node_cum[src];
+        double lo_s = src > 0 ? (small ? readlane_f64(node_cum_reg, src - 1) : P.node_cum[src - 1]) : 0.0;
         double w_s = hi_s - lo_s;
         double x = u3 * (total - w_s);
         if (x >= lo_s) x += w_s;
-        dst = cum_search(c, P.node_cum, c.node_cum_reg, n, x);
+        dst = cum_search(c, P.node_cum, node_cum_reg, n, x);
         if (dst == src) dst = (src + 1 < n) ? src + 1 : src - 1;
         if (P.bit_rate_mode == 0) {
             const int nb = P.n_bit_rates;
-            double tb = nb <= kWave ? readlane_f64(c.br_cum_reg, nb - 1) : P.bit_rate_cum[nb - 1];
-            bi = cum_search(c, P.bit_rate_cum, c.br_cum_reg, nb, u4 * tb);
-            br = nb <= kWave ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.br_reg), bi)) : (float)P.bit_rates[bi];
+            double tb = nb <= kWave ? readlane_f64(br_cum_reg, nb - 1) : P.bit_rate_cum[nb - 1];
+            bi = cum_search(c, P.bit_rate_cum, br_cum_reg, nb, u4 * tb);
+            br = nb <= kWave ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(br_reg), bi)) : (float)P.bit_rates[bi];
         } else {
             int span = P.br_hi - P.br_lo + 1;
             int k = (int)(u4 * (double)span);
@@ -1768,10 +1773,6 @@ __device__ __forceinline__ void load_state(Ctx &c) {
     int words = P.n_links * P.row_words;
     const uint64_t *g = P.occ + (size_t)c.replica * words;
     for (int i = c.lane; i < words; i += kWave) c.occ[i] = g[i];
-    // traffic tables, one entry per lane (ballot search in draw_next)
-    c.node_cum_reg = (c.lane < P.n_nodes && P.n_nodes <= kWave) ? P.node_cum[c.lane] : INFINITY;
-    c.br_cum_reg = (c.lane < P.n_bit_rates && P.n_bit_rates <= kWave) ? P.bit_rate_cum[c.lane] : INFINITY;
-    c.br_reg = (c.lane < P.n_bit_rates && P.n_bit_rates <= kWave) ? (float)P.bit_rates[c.lane] : 0.f;
     wave_sync();
     c.active = c.e->st.active;
     c.osnr_prod = c.e->osnr_prod > 0.0 ? c.e->osnr_prod : 1.0;
