@@ -8,7 +8,9 @@
  * Parity status: PINNED.  The reference ships no golden vectors for this path, so the oracle is pinned
  * against outputs of the reference itself, generated in the build container by tests/golden/make_golden.py (the
  * reference compiled unmodified under /tmp) and committed as data under tests/golden/: GN known-answer tests,
- * candidate-scan cases, action codec cases, and full first-fit trajectories (tests/test_oracle_golden.py).
+ * candidate-scan cases, action codec cases, full trajectories (first fit, load balancing, highest SNR, with
+ * measure_disruptions and with defragmentation), observation vectors + action masks, and the per-state decisions of
+ * the remaining heuristics (tests/test_oracle_golden.py).
  *
  * It deliberately keeps the reference's data structures and operation order — int32 slot grid with 1 = free, per-link
  * running-service lists in insertion order, a binary heap of departures, fp64 GN model looped span by span — so that
