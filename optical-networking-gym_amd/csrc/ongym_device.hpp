@@ -220,9 +220,9 @@ __device__ __forceinline__ const __attribute__((address_space(1))) T *G(const T 
 // keeps the program order across the point: a wavefront-scope fence (emits no s_waitcnt) around a wave barrier.
 // (__syncthreads() would emit `s_waitcnt vmcnt(0) lgkmcnt(0)` and so also wait for every global load in flight.)
 __device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 }
 
 // ---------------------------------------------------------------------------------------------------------------
