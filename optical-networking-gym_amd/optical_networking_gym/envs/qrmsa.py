@@ -230,6 +230,9 @@ class QRMSAEnv:
         self._dev.reset()
         self.topology.graph["services"] = []
         self._accepted_by_id = {}
+        for u, v in self.topology.edges():     # qrmsa.pyx:475-495
+            link = self.topology[u][v]
+            link["utilization"] = link["last_update"] = link["external_fragmentation"] = link["compactness"] = 0.0
         self.max_modulation_idx = len(self.modulations) - 1
         self._pull_request()
         self._refresh_views()
@@ -393,6 +396,50 @@ class QRMSAEnv:
         grid = self._dev.grid(0)
         route = self.k_shortest_paths[self.current_service.source, self.current_service.destination][path]
         return [grid[self.topology[l.node1][l.node2]["index"], :] for l in route.links]
+
+    def _update_link_stats(self, node1, node2) -> None:
+        """Time-weighted utilisation / external fragmentation / compactness of one link (qrmsa.pyx:1353-1480), written
+        to the edge attributes like the reference.  Host-side arithmetic on the device's grid view; nothing in the
+        reference calls it, it is kept for scripts that do.  Its naming quirks are kept: the "total unused slots" of
+        the fragmentation term is the number of USED slots, the compactness divisor counts used BLOCKS."""
+        link = self.topology[node1][node2]
+        last_update = link["last_update"]
+        last_fragmentation = link.get("external_fragmentation", 0.0)
+        last_compactness = link.get("compactness", 0.0)
+        now = self.current_time
+        time_diff = now - last_update
+        row = np.asarray(self.topology.graph["available_slots"][link["index"], :], dtype=np.int32)
+        free = int(row.sum())
+        if now > 0:
+            cur_util = (self.num_spectrum_resources - free) / self.num_spectrum_resources
+            link["utilization"] = ((link["utilization"] * last_update) + (cur_util * time_diff)) / now
+        starts, values, lengths = rle(row)
+        free_runs = np.flatnonzero(values == 1)
+        if len(free_runs) > 1 and free_runs.tolist() != [0, len(values) - 1]:
+            max_empty = int(lengths[free_runs].max())
+        else:
+            max_empty = 0
+        if free > 0:
+            with np.errstate(divide="ignore", invalid="ignore"):   # an idle link divides 0 by 0 here, like the reference
+                cur_fragmentation = float(1.0 - np.float64(max_empty) / np.float64(row.shape[0] - free))
+        else:
+            cur_fragmentation = 1.0
+        used_runs = np.flatnonzero(values == 0)
+        cur_compactness = 1.0
+        if len(used_runs) > 1:
+            lo = int(starts[used_runs[0]])
+            hi = int(starts[used_runs[-1]] + lengths[used_runs[-1]])
+            _, inner_values, _ = rle(row[lo:hi])
+            used_blocks = float(np.sum(1 - inner_values))
+            used_slots = float(np.sum(1 - row))
+            if used_blocks > 0 and used_slots > 0:
+                cur_compactness = ((hi - lo) / used_slots) * (1.0 / used_blocks)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            link["external_fragmentation"] = float(
+                (np.float64(last_fragmentation * last_update) + np.float64(cur_fragmentation * time_diff)) / np.float64(now))
+            link["compactness"] = float(
+                (np.float64(last_compactness * last_update) + np.float64(cur_compactness * time_diff)) / np.float64(now))
+        link["last_update"] = now
 
     def policy_action(self, policy: int = nat.POLICY_FIRST_FIT):
         """A fused device policy evaluated on the current request: (action, blocked_resources, blocked_osnr)."""

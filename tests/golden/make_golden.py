@@ -540,6 +540,53 @@ def run_decisions(tag, topo_name, seed, load, S, warm, steps, driver, observers=
           ", ".join(f"{n} differs from driver {(out['dec_' + n][:, 0] != d[:, 0]).sum()}x" for n in observers))
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# link statistics (_update_link_stats, qrmsa.pyx:1353-1480): no caller inside the reference, pinned by calling it directly
+# ----------------------------------------------------------------------------------------------------------------
+def run_link_stats(tag, topo_name="nsfnet", seed=31, load=400, S=320, steps=420, at=(60, 200, 419)):
+    topo = load_topology(topo_name, 5)
+    random.Random = seeded_random(seed)
+    try:
+        env = QRMSAEnvWrapper(
+            topology=topo, seed=10, allow_rejection=True, load=load, episode_length=steps + 50, num_spectrum_resources=S,
+            launch_power_dbm=0.0, bandwidth=S * 12.5e9, frequency_start=3e8 / 1565e-9, frequency_slot_bandwidth=12.5e9,
+            bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), margin=0.0, file_name="",
+            measure_disruptions=False, k_paths=5, modulations_to_consider=6, defragmentation=False, n_defrag_services=0,
+            gen_observation=False)
+    finally:
+        random.Random = _OrigRandom
+    reqs, kinds = [request_tuple(env)], [0]
+    env.reset()
+    reqs.append(request_tuple(env)); kinds.append(0)
+    actions, checks = [], []
+    edges = list(env.env.topology.edges())
+    for i in range(steps):
+        a = H.heuristic_shortest_available_path_first_fit_best_modulation(env)[0]
+        env.step(int(a))
+        actions.append(int(a))
+        reqs.append(request_tuple(env)); kinds.append(1)
+        if i in at:
+            # (_get_network_compactness(), qrmsa.pyx:1150-1186, segfaults in the compiled reference: not captured)
+            rows = []
+            for u, v in edges:
+                env.env._update_link_stats(u, v)
+                link = env.env.topology[u][v]
+                rows.append([float(link["utilization"]), float(link["external_fragmentation"]),
+                             float(link["compactness"]), float(link["last_update"])])
+            checks.append(dict(step=i, current_time=float(env.env.current_time), links=rows))
+    reqs_a = np.array(reqs, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, f"{tag}.npz"),
+                        req_at=reqs_a[:, 0].astype(np.float32), req_ht=reqs_a[:, 1].astype(np.float32),
+                        req_src=reqs_a[:, 2].astype(np.int32), req_dst=reqs_a[:, 3].astype(np.int32),
+                        req_br=reqs_a[:, 4].astype(np.float32), req_kind=np.array(kinds, dtype=np.uint8),
+                        st_action=np.array(actions, np.int32))
+    meta = dict(tag=tag, topology=topo_name, seed=seed, load=load, S=S, steps=steps, episode_length=steps + 50,
+                edges=[[str(u), str(v)] for u, v in edges], checks=checks, bit_rates=[10, 40, 100, 400])
+    json.dump(meta, open(os.path.join(HERE, f"{tag}.json"), "w"), indent=1)
+    print(f"{tag}: {steps} steps, checks at {[c['step'] for c in checks]}, mean utilization "
+          f"{[round(float(np.mean([r[0] for r in c['links']])), 4) for c in checks]}")
+
+
 CHEAP = ("shortest_available_path_lowest_spectrum_best_modulation", "best_modulation_load_balancing",
          "heuristic_load_balancing_first_fit", "heuristic_mscl_simplified", "heuristic_mscl_sequential_simplified",
          "psr_c", "psr_o", "heuristic_exact_fit")
@@ -612,6 +659,8 @@ def main():
     for tag, kw in DEC.items():
         if not want or tag in want:
             run_decisions(tag, **kw)
+    if not want or "linkstats_nsfnet320" in want:
+        run_link_stats("linkstats_nsfnet320")
 
 
 if __name__ == "__main__":

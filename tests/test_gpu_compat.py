@@ -221,3 +221,34 @@ def test_defragmentation_through_the_wrapper():
     services = sim.topology.graph["services"]
     assert len(services) == ti["n_services"] and d["st_drea"][i - 1] > 20
     assert sum(s.OSNR for s in services) / len(services) == pytest.approx(ti["mean_gsnr"], rel=1e-9)
+
+
+def test_link_statistics_like_the_reference():
+    """_update_link_stats (qrmsa.pyx:1353-1480) on the device-backed env against values obtained by calling the
+    reference's method on the same states (tests/golden/linkstats_nsfnet320.*).  (_get_network_compactness, :1150-1186,
+    segfaults in the compiled reference and is not provided.)"""
+    import json, os
+    from common import GOLDEN
+    meta = json.load(open(os.path.join(GOLDEN, "linkstats_nsfnet320.json")))
+    d = np.load(os.path.join(GOLDEN, "linkstats_nsfnet320.npz"))
+    topology = get_topology(bundled_topology_path("nsfnet_chen.txt"), None, jocn_modulations(), 80, 0.2, 4.5, 5)
+    env = QRMSAEnvWrapper(topology=topology, seed=10, allow_rejection=True, load=meta["load"],
+                          episode_length=meta["episode_length"], num_spectrum_resources=meta["S"], launch_power_dbm=0.0,
+                          bandwidth=meta["S"] * 12.5e9, frequency_start=3e8 / 1565e-9, frequency_slot_bandwidth=12.5e9,
+                          bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), margin=0, file_name="", k_paths=5,
+                          modulations_to_consider=6, gen_observation=False, requests=traj_requests(d))
+    env.reset()
+    sim = get_qrmsa_env(env)
+    checks = {c["step"]: c for c in meta["checks"]}
+    assert [list(map(str, e)) for e in sim.topology.edges()] == meta["edges"]
+    for i, action in enumerate(d["st_action"]):
+        got = heuristic_shortest_available_path_first_fit_best_modulation(env)[0]
+        assert got == action
+        env.step(int(action))
+        if i in checks:
+            assert sim.current_time == checks[i]["current_time"]
+            for (u, v), want in zip(sim.topology.edges(), checks[i]["links"]):
+                sim._update_link_stats(u, v)
+                link = sim.topology[u][v]
+                have = [link["utilization"], link["external_fragmentation"], link["compactness"], link["last_update"]]
+                np.testing.assert_allclose(have, want, rtol=1e-12, atol=1e-15)
