@@ -597,14 +597,15 @@ __device__ __forceinline__ void policy_first_fit(Ctx &c, int src, int dst, doubl
         if (k == 0) { p.id = path; p.hops = c.pre_hops; p.mylink = c.pre_mylink; p.m0 = c.pre_m0; p.m1 = c.pre_m1; p.ase = c.pre_ase; p.w1 = c.pre_w1; }
         else p = load_path(c, path);
         c.paths_tried++; c.path_hops += p.hops;
-        const uint64_t free_ext = path_free_ext(c, p);
+        // run-AND of length r, extended modulation by modulation (the bitmap itself is not kept alive across the GN
+        // evaluation: the rare restart below recomputes it)
+        uint64_t runs = path_free_ext(c, p);
         STAMP(c, 1);
-        uint64_t runs = free_ext;   // run-AND of length r, extended modulation by modulation
         int r = 1, L = -1;
         for (int m = max_mod; m >= 0; m--) {
             int n = uniform_i32(c.nreq[m]);
             if (n <= 0) continue;
-            if (n + 1 < r) { runs = free_ext; r = 1; }   // slot counts normally grow as the modulation index falls
+            if (n + 1 < r) { runs = path_free_ext(c, p); r = 1; }   // slot counts normally grow as the modulation index falls
             runs = run_and(runs, r, n + 1);
             int first = first_set(runs);
             STAMP(c, 2);
