@@ -582,3 +582,46 @@ def test_misc_fused_policies_vs_oracle_random_traffic(pid):
     assert rejected > 5
     if pid == 9:
         assert retried > 50
+
+
+def test_long_wide_sweep_final_state_vs_oracle():
+    """256 replicas x 3 000 steps (three episodes) with launch power -7..+7 dBm, load 120..900 Erlang and margins 0..2 dB
+    spread over the replicas: every replica's final grid, clocks and counters against the oracle (OpenMP over replicas).
+    A single differing accept/slot decision anywhere in the 768 000 steps would show up in these."""
+    from oracle_lib import batch_run_first_fit
+    B, steps = 256, 3000
+    rng = np.random.default_rng(42)
+    loads = rng.uniform(120, 900, B)
+    lps = rng.uniform(-7.0, 7.0, B)
+    margins = rng.choice([0.0, 0.25, 1.0, 2.0], B)
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=320, batch=B, capacity=1024, episode_length=1000,
+              auto_reset=True, load=300, bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400, 1000),
+              replica_load=loads, replica_launch_power_dbm=lps, replica_margin=margins)
+    holder = nat.ConfigHolder(golden_tables("nsfnet"), **kw)
+    env = BatchedQRMSAEnv(tables=golden_tables("nsfnet"), modulations=jocn_modulations(), batch_size=B,
+                          num_spectrum_resources=320, capacity=1024, episode_length=1000, auto_reset=True, load=300,
+                          bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400, 1000), replica_load=loads,
+                          replica_launch_power_dbm=lps, replica_margin=margins)
+    env.seed(99); env.reset()
+    for _ in range(steps // 500):
+        env.step_policy(500, record=False)
+    st = env.stats()
+    oracles = []
+    for r in range(B):
+        o = OracleEnv(holder, replica=r)
+        o.seed(99); o.reset()
+        oracles.append(o)
+    assert batch_run_first_fit(oracles, steps, 16) == B * steps
+    blocked = 0
+    for r, o in enumerate(oracles):
+        so = o.stats()
+        for f in ("services_processed", "services_accepted", "episode_services_accepted", "rejected",
+                  "bit_rate_provisioned", "episode_bit_rate_provisioned", "episodes_completed", "current_time", "active",
+                  "last_episode_accepted", "last_service_blocking_rate", "last_bit_rate_blocking_rate",
+                  "total_paths_tried", "total_path_hops", "total_active_sum"):
+            assert st[r][f] == so[f], (r, f, st[r][f], so[f], loads[r], lps[r], margins[r])
+        np.testing.assert_array_equal(st[r]["last_modulation_hist"], so["last_modulation_hist"])
+        assert st[r]["last_mean_gsnr"] == pytest.approx(so["last_mean_gsnr"], rel=1e-9)
+        np.testing.assert_array_equal(env.grid(r), o.grid())
+        blocked += int(so["total_steps"] - so["total_accepted"])
+    assert blocked > 50000          # the sweep does reach heavily blocked regimes
