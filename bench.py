@@ -26,7 +26,7 @@ import numpy as np  # noqa: E402
 WORKLOADS = {
     # BASELINE.json metric: QRMSA NSFNET-320, k=5, load 300 (SURVEY §8d synthetic inputs), JOCN modulation set
     "nsfnet320": dict(topology="nsfnet_chen.txt", S=320, load=300.0, capacity=448, bit_rates=(10, 40, 100, 400)),
-    "cost239_320": dict(topology="cost239.txt", S=320, load=400.0, capacity=640, bit_rates=(10, 40, 100, 400)),
+    "cost239_320": dict(topology="cost239.txt", S=320, load=400.0, capacity=512, bit_rates=(10, 40, 100, 400)),
     "nobeleu768": dict(topology="nobel-eu.txt", S=768, load=600.0, capacity=704, bit_rates=(10, 40, 100, 400)),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
