@@ -587,6 +587,26 @@ def run_link_stats(tag, topo_name="nsfnet", seed=31, load=400, S=320, steps=420,
           f"{[round(float(np.mean([r[0] for r in c['links']])), 4) for c in checks]}")
 
 
+def export_utils_kats():
+    """utils.pyx:44-110 on random rows (pure functions): rle, link_shannon_entropy_, fragmentation_route_cuts/_rss."""
+    from optical_networking_gym import utils as U
+    rng = np.random.default_rng(5)
+    cases = []
+    for i in range(40):
+        n_rows, width = int(rng.integers(1, 6)), int(rng.integers(4, 90))
+        p = float(rng.uniform(0.1, 0.9))
+        rows = (rng.random((n_rows, width)) < p).astype(np.int32)
+        if i == 0: rows[:] = 1
+        if i == 1: rows[:] = 0
+        starts, values, lengths = U.rle(rows[0])
+        cases.append(dict(rows=rows.tolist(), rle=[np.asarray(starts).tolist(), np.asarray(values).tolist(), np.asarray(lengths).tolist()],
+                          entropy=[float(U.link_shannon_entropy_(r.tolist())) for r in rows],
+                          cuts=int(U.fragmentation_route_cuts([r.tolist() for r in rows])),
+                          rss=float(U.fragmentation_route_rss([r.tolist() for r in rows]))))
+    json.dump(dict(cases=cases), open(os.path.join(HERE, "kats_utils.json"), "w"))
+    print(f"kats_utils: {len(cases)} cases")
+
+
 CHEAP = ("shortest_available_path_lowest_spectrum_best_modulation", "best_modulation_load_balancing",
          "heuristic_load_balancing_first_fit", "heuristic_mscl_simplified", "heuristic_mscl_sequential_simplified",
          "psr_c", "psr_o", "heuristic_exact_fit")
@@ -650,6 +670,8 @@ def main():
             export_tables(name)
     if not want or "kats" in want:
         export_kats()
+    if not want or "kats_utils" in want:
+        export_utils_kats()
     for tag, kw in TRAJ.items():
         if not want or tag in want:
             run_trajectory(tag, **kw)

@@ -218,3 +218,18 @@ def test_span_link_and_rmsa_plumbing():
     env = RMSAEnv(topology=topology, num_spectrum_resources=360)
     assert env.spectrum_use.shape == (22, 360) and topology.name == "NSFNET"
     assert len(topology.graph["ksp"]["1", "13"]) == 5 and topology.graph["ksp"]["1", "13"][0].hops == 3
+
+
+def test_fragmentation_helpers_match_the_reference():
+    """utils.rle / link_shannon_entropy_ / fragmentation_route_cuts / fragmentation_route_rss (utils.pyx:44-110) against
+    values computed by the reference's own functions on random rows (tests/golden/kats_utils.json)."""
+    from optical_networking_gym.utils import (fragmentation_route_cuts, fragmentation_route_rss, link_shannon_entropy_, rle)
+    cases = json.load(open(os.path.join(GOLDEN, "kats_utils.json")))["cases"]
+    assert len(cases) == 40
+    for c in cases:
+        rows = np.array(c["rows"], np.int32)
+        starts, values, lengths = rle(rows[0])
+        assert [starts.tolist(), values.tolist(), lengths.tolist()] == c["rle"]
+        assert [link_shannon_entropy_(r.tolist()) for r in rows] == c["entropy"]
+        assert fragmentation_route_cuts([r.tolist() for r in rows]) == c["cuts"]
+        assert fragmentation_route_rss([r.tolist() for r in rows]) == c["rss"]
