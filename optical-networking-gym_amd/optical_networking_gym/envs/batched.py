@@ -36,7 +36,13 @@ class BatchedQRMSAEnv:
         if not modulations:
             raise ValueError("no modulations: pass `modulations=` or build the topology with them")
         mtc = kwargs.pop("modulations_to_consider", 6)
-        modulations = list(modulations)[:min(mtc, len(modulations))] if mtc < len(modulations) else list(modulations)
+        modulations = list(modulations)
+        if mtc < len(modulations):
+            # the reference's action codec then addresses only the top `mtc` formats (qrmsa.pyx:801-834) while its heuristics
+            # still walk all of them and encode the others out of range (heuristics.py:36-54): no consistent behaviour to
+            # reproduce. Pass the formats you want considered instead.
+            raise NotImplementedError("modulations_to_consider < len(modulations) is not supported: build the topology "
+                                      "with the modulation formats to consider")
         for dead in ("seed", "allow_rejection", "reset", "file_name", "blocks_to_consider", "gen_observation",
                      "bands", "bandwidth", "k_paths"):
             kwargs.pop(dead, None)

@@ -148,6 +148,8 @@ def test_unbuilt_features_fail_loudly():
     topology = get_topology(bundled_topology_path("nsfnet_chen.txt"), None, jocn_modulations(), 80, 0.2, 4.5, 5)
     with pytest.raises(NotImplementedError):
         QRMSAEnvWrapper(topology=topology, load=300, gen_observation=True)
+    with pytest.raises(NotImplementedError, match="modulations_to_consider"):
+        QRMSAEnvWrapper(topology=topology, load=300, gen_observation=False, modulations_to_consider=3)
     import networkx as nx
     with pytest.raises(KeyError, match="ksp"):
         QRMSAEnvWrapper(topology=nx.Graph(), gen_observation=False)
