@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
-"""RL-style loop on device buffers (BASELINE config 5 shape, without a learner): observation + action mask ->
-masked random policy in PyTorch-ROCm -> step(actions). The env writes into / reads from torch CUDA tensors through
-`io_device=1` (torch.Tensor.data_ptr()), nothing crosses PCIe inside the loop.
+"""RL-style loop on device buffers (BASELINE config 5 shape): observation + action mask -> masked policy in
+PyTorch-ROCm -> step(actions).  Default: a masked random policy (env-side cost only).  `--learner`: a masked
+actor-critic MLP (368 -> 512 -> 512 -> 9601 logits + value head, bf16 autocast) sampled every step and updated with
+Adam on n-step returns every `--horizon` steps - the end-to-end steps/s of an on-device training loop (no PPO library
+is installed in the image; this is the same data flow: rollout, masked log-probs, advantage, backward, optimizer).
+The env writes into / reads from torch CUDA tensors through `io_device=1` (torch.Tensor.data_ptr()), nothing crosses PCIe inside the loop.
 
-    python tools/bench_rl.py [--batch 16384] [--steps 200]
+    python tools/bench_rl.py [--batch 16384] [--steps 200] [--learner [--horizon 16]]
 """
 import argparse
 import os
@@ -21,6 +24,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=16384)
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--warmup", type=int, default=300)
+ap.add_argument("--learner", action="store_true")
+ap.add_argument("--horizon", type=int, default=16)
 args = ap.parse_args()
 B = args.batch
 wl = bench.WORKLOADS["nsfnet320"]
@@ -50,12 +55,51 @@ def rl_step():
     env.sync()
 
 
-for _ in range(5):
+if args.learner:
+    torch.manual_seed(0)
+    body = torch.nn.Sequential(torch.nn.Linear(obs_dim, 512), torch.nn.Tanh(), torch.nn.Linear(512, 512), torch.nn.Tanh()).to(dev)
+    pi_head, v_head = torch.nn.Linear(512, nact).to(dev), torch.nn.Linear(512, 1).to(dev)
+    params = list(body.parameters()) + list(pi_head.parameters()) + list(v_head.parameters())
+    opt = torch.optim.Adam(params, lr=3e-4)
+    r_off = nat.STEP_DTYPE.fields["reward"][1]
+    logps, values, rewards = [], [], []
+
+    def rl_step():   # noqa: F811
+        env._check(env.lib.ongym_observe(env._h, obs.data_ptr(), mask.data_ptr()), "observe")
+        env.sync()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            h = body(obs)
+            logits, v = pi_head(h).float(), v_head(h).float().squeeze(1)
+        logits = logits.masked_fill(mask == 0, -1e9)
+        dist_ = torch.distributions.Categorical(logits=logits)
+        a = dist_.sample()
+        actions.copy_(a.to(torch.int32))
+        torch.cuda.synchronize()
+        env._check(env.lib.ongym_step_actions(env._h, actions.data_ptr(), recs.data_ptr()), "step")
+        env.sync()
+        logps.append(dist_.log_prob(a)); values.append(v)
+        rewards.append(recs[:, r_off:r_off + 8].contiguous().view(torch.float64).squeeze(1).float())
+        if len(rewards) == args.horizon:
+            ret, rets = torch.zeros(B, device=dev), []
+            for r in reversed(rewards):
+                ret = r + 0.99 * ret
+                rets.append(ret)
+            rets = torch.stack(rets[::-1]); vs = torch.stack(values); lp = torch.stack(logps)
+            adv = (rets - vs).detach()
+            loss = -(lp * adv).mean() + 0.5 * (rets - vs).pow(2).mean()
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            logps.clear(); values.clear(); rewards.clear()
+
+for _ in range(5 if not args.learner else args.horizon):
     rl_step()
 t0 = time.perf_counter()
 for _ in range(args.steps):
     rl_step()
 dt = time.perf_counter() - t0
 acc = recs.cpu().numpy().view(nat.STEP_DTYPE)["accepted"].mean()
-print(f"B={B}: {B * args.steps / dt:.3e} RL env-steps/s (observe + masked sampling in torch + step), "
+what = "observe + actor-critic MLP forward/sample + step + Adam update every %d steps" % args.horizon if args.learner \
+    else "observe + masked sampling in torch + step"
+print(f"B={B}: {B * args.steps / dt:.3e} RL env-steps/s ({what}), "
       f"{dt / args.steps * 1e3:.2f} ms per batched step, accepted {acc:.3f}")
