@@ -513,8 +513,18 @@ __device__ __forceinline__ GnLin gn_eval(Ctx &c, const PathRef &p, int L, int s,
             }
             double w1 = 0.0, w2 = 0.0;
             if (R32) {
+                // every listed interferer shares at least one link; the weights of the first TWO shared links are read
+                // together (one LDS round trip instead of two), further ones - rare - in the loop
                 uint32_t m = (uint32_t)m0;
                 terms += __popc(m);
+                const int l0 = __ffs(m) - 1;
+                m &= m - 1;
+                const bool two = m != 0;
+                const int l1 = two ? __ffs(m) - 1 : l0;
+                const double a0 = c.lw[2 * l0], b0 = c.lw[2 * l0 + 1], a1 = c.lw[2 * l1], b1 = c.lw[2 * l1 + 1];
+                m &= m - 1;
+                w1 = a0 + (two ? a1 : 0.0);
+                w2 = b0 + (two ? b1 : 0.0);
                 while (m) { int l = __ffs(m) - 1; m &= m - 1; w1 += c.lw[2 * (l)]; w2 += c.lw[2 * (l) + 1]; }
             } else {
                 terms += __popcll((unsigned long long)m0) + __popcll((unsigned long long)m1);
