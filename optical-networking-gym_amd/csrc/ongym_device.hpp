@@ -109,8 +109,8 @@ struct Params {
 
 // ---------------------------------------------------------------------------------------------------------------
 // LDS carve-up (dynamic shared memory), 8-byte aligned pieces first
-//   occ u64[E*W] | lw f64[2E] (w1, w2 interleaved) | lcl f64[E] | lsc f64[E] | DevEnv | sa u32[C] | sb u32[C] | sr f32[C] |
-//   lim f64[8] | rp f64[2] | phi f64[8] | nlic f64[8] | selfa f64[8] | nreq i32[8] | list u16[C] |
+//   DevEnv | lim f64[8] | rp f64[2] | phi f64[8] | nlic f64[8] | selfa f64[8] | nreq i32[8] |      (fixed size, constant addresses)
+//   occ u64[E*W] | lw f64[2E] (w1, w2 interleaved) | lcl f64[E] | lsc f64[E] | sa u32[C] | sb u32[C] | sr f32[C] | list u16[C] |
 //   (lim0 f64[8] when measure_disruptions or defragmentation) | (so f64[C] | sq u32[C] when defragmentation)
 // (DevEnv = its first kEnvHotBytes)
 // ---------------------------------------------------------------------------------------------------------------
@@ -187,22 +187,24 @@ struct Ctx {
 
 __device__ __forceinline__ void ctx_bind(Ctx &c, unsigned char *smem) {
     const Params &P = c.P;
-    c.occ = reinterpret_cast<uint64_t *>(smem);
-    c.lw = reinterpret_cast<double *>(c.occ + (size_t)P.n_links * P.row_words);
-    // the per-link alpha tables exist only when the attenuation is not uniform
-    c.lcl = c.lw + 2 * P.n_links;
-    c.lsc = c.lcl + (P.uniform_alpha ? 0 : P.n_links);
-    c.e = reinterpret_cast<DevEnv *>(c.lsc + (P.uniform_alpha ? 0 : P.n_links));
-    c.sa = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(c.e) + kEnvHotBytes);
-    c.sb = c.sa + P.capacity;
-    c.sr = reinterpret_cast<float *>(c.sb + P.capacity);
-    c.lim = reinterpret_cast<double *>(c.sr + P.capacity);   // capacity is a multiple of 64 -> 8-byte aligned
+    // fixed-size pieces first: their LDS addresses are link-time constants (immediate offsets, no scalar registers)
+    c.e = reinterpret_cast<DevEnv *>(smem);
+    c.lim = reinterpret_cast<double *>(smem + kEnvHotBytes);
     c.rp = c.lim + 8;
     c.phi = c.rp + 2;
     c.nlic = c.phi + 8;
     c.selfa = c.nlic + 8;
     c.nreq = reinterpret_cast<int *>(c.selfa + 8);
-    c.list = reinterpret_cast<uint16_t *>(c.nreq + 8);
+    // then the pieces whose size depends on the configuration
+    c.occ = reinterpret_cast<uint64_t *>(c.nreq + 8);
+    c.lw = reinterpret_cast<double *>(c.occ + (size_t)P.n_links * P.row_words);
+    // the per-link alpha tables exist only when the attenuation is not uniform
+    c.lcl = c.lw + 2 * P.n_links;
+    c.lsc = c.lcl + (P.uniform_alpha ? 0 : P.n_links);
+    c.sa = reinterpret_cast<uint32_t *>(c.lsc + (P.uniform_alpha ? 0 : P.n_links));
+    c.sb = c.sa + P.capacity;
+    c.sr = reinterpret_cast<float *>(c.sb + P.capacity);
+    c.list = reinterpret_cast<uint16_t *>(c.sr + P.capacity);
     c.lim0 = reinterpret_cast<double *>(c.list + P.capacity);   // capacity % 64 == 0 -> 8-byte aligned; only if enabled
     c.so = c.lim0 + 8;                                          // only with defragmentation
     c.sq = reinterpret_cast<uint32_t *>(c.so + P.capacity);
