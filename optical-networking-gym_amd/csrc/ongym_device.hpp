@@ -603,11 +603,10 @@ __device__ __forceinline__ void policy_first_fit(Ctx &c, int src, int dst, doubl
     ch.path = -1; ch.m0 = 0; ch.g.ase = ch.g.nli = 0.0;
     int bres = 0, bosnr = 0;
     for (int k = 0; k < P.k_paths; k++) {
-        int path = k == 0 ? c.pre_id : G(P.pair_paths)[(src * P.n_nodes + dst) * P.k_paths + k];
+        int path = k == 0 ? c.pre_id : G(P.pair_paths)[(src * P.n_nodes + dst) * P.k_paths + k];   // id looked up at draw time
         if (path < 0) break;
         PathRef p;
-        if (k == 0) { p.id = path; p.hops = c.pre_hops; p.mylink = c.pre_mylink; p.m0 = c.pre_m0; p.m1 = c.pre_m1; p.ase = c.pre_ase; p.w1 = c.pre_w1; }
-        else p = load_path(c, path);
+        p = load_path(c, path);
         c.paths_tried++; c.path_hops += p.hops;
         // run-AND of length r, extended modulation by modulation (the bitmap itself is not kept alive across the GN
         // evaluation: the rare restart below recomputes it)
