@@ -18,7 +18,8 @@ def main():
     ap.add_argument("-l", "--load", type=float, default=210)
     ap.add_argument("-s", "--episode_length", type=int, default=1000)
     ap.add_argument("-th", "--threads", type=int, default=64, help="parallel simulations (replicas) per margin")
-    ap.add_argument("-hi", "--heuristic_index", type=int, default=1, choices=[1, 2, 4])
+    ap.add_argument("-hi", "--heuristic_index", type=int, default=1, choices=[1, 2, 4],
+                    help="1: first fit, 2: highest SNR, 4: load balancing best modulation (graph_load.py numbering)")
     ap.add_argument("-mf", "--monitor_file_name", default="examples/JOCN_Benchmark_2024/results/mr_episodes")
     ap.add_argument("--launch_power", type=float, default=0.0)
     ap.add_argument("--seed", type=int, default=20)
