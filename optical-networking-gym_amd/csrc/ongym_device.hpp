@@ -386,6 +386,7 @@ __device__ __forceinline__ uint64_t path_free_ext(const Ctx &c, const PathRef &p
 }
 
 // set (free_=true) or clear the slots [lo, hi) on every link of the path; lane h owns link h.
+template <bool SYNC = true>
 __device__ __forceinline__ void mark_links(Ctx &c, int hops, int mylink, int lo, int hi, bool free_) {
     const Params &P = c.P;
     if (hi > P.n_slots) hi = P.n_slots;
@@ -396,7 +397,7 @@ __device__ __forceinline__ void mark_links(Ctx &c, int hops, int mylink, int lo,
             c.occ[mylink * P.row_words + w] = free_ ? (v | m) : (v & ~m);
         }
     }
-    wave_sync();
+    if (SYNC) wave_sync();   // SYNC = false: the caller orders a later wave_sync before anything reads the bitmap again
 }
 
 // same, for a path given as a link mask (links < 32): lane l owns link l.
@@ -1350,7 +1351,7 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
     if (outcome == 0) {
         // _provision_path (:1288-1325): occupy n slots + one guard slot unless the allocation ends at S
         int end = ch.slot + ch.n; if (end < P.n_slots) end += 1;
-        mark_links(c, ch.hops, ch.mylink, ch.slot, end, false);
+        mark_links<false>(c, ch.hops, ch.mylink, ch.slot, end, false);   // ordered by the wave_sync after the bookkeeping
     }
     STAMP(c, 5);
     if (c.lane == 0) {
