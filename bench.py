@@ -1,20 +1,30 @@
 #!/usr/bin/env python3
 """bench.py — env-steps/s of the fused first-fit policy + step loop (graph_load.py:161-163 of the reference) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workload NAME] [--scaling weak|strong]
 
-A "step" is one batched env-step: every one of the B replicas on a GPU processes one service request (policy + step +
-next-request generation + departures).  Weak scaling: every rank owns B replicas on its own GPU (one process per GPU);
-the replicas are independent, so the only collective is the RCCL all-reduce of the statistics vector after the timed
-region.  Inputs are generated on device (counter-based traffic stream, include/ongym_traffic.h) and the whole state is
-resident in HBM when the timed region starts.  Prints ONE JSON line on rank 0.
+A bench "step" is ONE LAUNCH of the hot path: every replica on the GPU processes `--steps-per-launch` (250) service
+requests (policy + step + next-request generation + departures) with its state resident on the CU.  The metric stays
+env-steps/s = requests/s summed over replicas and GPUs; `config.env_steps_per_bench_step` says how many a step holds.
+Before anything is timed the network is always filled by >= one whole episode (999 env-steps per replica, untimed), so
+the measured state does not depend on --warmup/--steps: the timed region runs on the steady-state episode mix of
+`graph_load.py:157-164` (whole episodes with auto-reset), never on a cold network.  `--warmup W` then adds W untimed
+bench steps and `--steps K` times exactly K of them between barrier + synchronize fences (max over ranks).
+
+Multi-GPU: one process per GPU.  Under `python -m torch.distributed.run` the ranks come from the environment; a plain
+`python bench.py --gpus N` spawns that launcher itself as a CHILD process before anything touches the GPU.  Replicas are
+independent: rank k owns the global replicas [k*B, (k+1)*B) (request stream = (seed, global replica index), so a sharded
+run simulates exactly the replicas of the unsharded one); the only collective is the RCCL all-reduce of the statistics
+vector after the timed region.  `--scaling weak`: B = --batch per GPU; `--scaling strong`: --batch is the GLOBAL batch.
+Inputs are generated on device (include/ongym_traffic.h) and all state is HBM-resident when the timed region starts.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,7 +39,15 @@ WORKLOADS = {
     "cost239_320": dict(topology="cost239.txt", S=320, load=400.0, capacity=512, bit_rates=(10, 40, 100, 400)),
     "nobeleu768": dict(topology="nobel-eu.txt", S=768, load=600.0, capacity=704, bit_rates=(10, 40, 100, 400)),
 }
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+# MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, a wave64 VALU instruction takes 2 cycles on its SIMD, 2.4 GHz max clock
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
+# reference (Cython) throughput measured in the build container, BASELINE.md §2 / SURVEY §6 (cannot travel to the GPU box)
+REFERENCE_MEASURED = {
+    "nsfnet320": {"steps_per_s_1core": 348.0, "steps_per_s_8procs": 2178.0},
+    "nobeleu768": {"steps_per_s_1core_nsfnet768_load600": 282.0, "steps_per_s_8procs_nsfnet768_load600": 1636.0},
+}
+MIN_FILL_ENV_STEPS = 999     # one whole episode (warm-up 1 episode)
 
 
 def jocn_modulations():
@@ -59,7 +77,19 @@ def algorithmic_bytes_per_step(stats_sum, S):
                    mean_active_services=A)
 
 
-def cpu_baseline(tables, wl, seconds_target=12.0):
+def pmc_summary(workload):
+    """Counter summary of the dominant kernel for this workload, from the rocprofv3 --pmc passes committed under
+    profiles/ (collected in separate runs as MI355X_MICROARCH.md prescribes; bench.py cannot run the profiler on
+    itself).  None when no profile of the current kernel is tracked."""
+    path = os.path.join(REPO, "profiles", "pmc_summary.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload)
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(tables, wl, workload, seconds_target=12.0):
     """The CPU oracle (C restatement of the reference, oracle/) on this box's host cores, bounded sample."""
     from optical_networking_gym import _native as nat
     from oracle_lib import OracleEnv, batch_run_first_fit
@@ -82,37 +112,57 @@ def cpu_baseline(tables, wl, seconds_target=12.0):
         dt = time.perf_counter() - t0
         if dt >= seconds_target or done >= 40 * 999 * nrep:
             break
-    return dict(value=done / dt, unit="env-steps/s", cores=threads, kind="port",
-                sample=f"{nrep} replicas x {done // nrep} steps of the same workload after a 999-step warm-up, "
-                       f"OpenMP over replicas, {dt:.1f} s")
+    out = dict(value=done / dt, unit="env-steps/s", cores=threads, kind="port",
+               sample=f"{nrep} replicas x {done // nrep} steps of the same workload after a 999-step warm-up, "
+                      f"OpenMP over replicas, {dt:.1f} s")
+    if workload in REFERENCE_MEASURED:
+        # the chain GPU -> port (timed here) -> reference (timed in the build container: it cannot travel)
+        out["reference_measured"] = dict(REFERENCE_MEASURED[workload], unit="env-steps/s",
+                                         where="build container, Xeon 2.1 GHz, 8 vCPU (BASELINE.md §2)")
+    return out
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a child process (nothing in this
+    process has touched the GPU), stream its output through and exit with its code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10000)
-    ap.add_argument("--warmup", type=int, default=1000)
-    ap.add_argument("--batch", type=int, default=65536, help="replicas per GPU")
+    ap.add_argument("--steps", type=int, default=40, help="timed bench steps (launches of --steps-per-launch env-steps)")
+    ap.add_argument("--warmup", type=int, default=4, help="untimed bench steps after the >= 1-episode fill")
+    ap.add_argument("--batch", type=int, default=65536, help="replicas per GPU (weak) or in total (strong)")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
     ap.add_argument("--workload", default="nsfnet320", choices=sorted(WORKLOADS))
     ap.add_argument("--steps-per-launch", type=int, default=250)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.steps <= 0 or args.warmup < 0 or args.steps_per_launch <= 0:
+        raise SystemExit("--steps and --steps-per-launch must be positive, --warmup non-negative")
 
+    if "RANK" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
 
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
-    from optical_networking_gym._dist import init_process_group, rank_seed, reduce_run_statistics
+    from optical_networking_gym._dist import init_process_group, reduce_run_statistics, shard_bounds
     # under torch.distributed.run (RANK set) the process group is always created, also for one rank
     dist = init_process_group("nccl", local_rank) if (world > 1 or "RANK" in os.environ) else None   # "nccl" = RCCL
 
@@ -124,26 +174,26 @@ def main():
     from optical_networking_gym.envs.batched import BatchedQRMSAEnv
 
     wl = WORKLOADS[args.workload]
+    spl = args.steps_per_launch
+    global_batch = args.batch * world if args.scaling == "weak" else args.batch
+    base, local_batch = shard_bounds(global_batch, rank, world)      # this rank's slice of the global replicas
     tables = build_tables(wl["topology"])
-    env = BatchedQRMSAEnv(tables=tables, modulations=jocn_modulations(), batch_size=args.batch, device=local_rank,
+    env = BatchedQRMSAEnv(tables=tables, modulations=jocn_modulations(), batch_size=local_batch, device=local_rank,
                           num_spectrum_resources=wl["S"], capacity=wl["capacity"], episode_length=1000,
                           auto_reset=True, load=wl["load"], bit_rate_selection="discrete", bit_rates=wl["bit_rates"])
-    env.seed(rank_seed(args.seed, rank))
+    env.seed(args.seed, replica_base=base)
     env.reset()
 
-    def run(nsteps, timed):
-        kernel_ms, launches = 0.0, 0
-        left = nsteps
-        while left > 0:
-            n = min(left, args.steps_per_launch)
-            env.step_policy(n, record=False)
+    def run(launches, timed):
+        kernel_ms = 0.0
+        for _ in range(launches):
+            env.step_policy(spl, record=False)
             if timed:
                 kernel_ms += env.last_kernel_ms()     # HIP events on the env's own stream
-                launches += 1
-            left -= n
-        return kernel_ms, launches
+        return kernel_ms
 
-    run(args.warmup, False)
+    fill_launches = -(-MIN_FILL_ENV_STEPS // spl)     # always: >= one whole episode, untimed
+    run(fill_launches + args.warmup, False)
     env.sync()
     s0 = env.stats()
 
@@ -154,7 +204,7 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    kernel_ms, launches = run(args.steps, True)
+    kernel_ms = run(args.steps, True)
     env.sync()
     fence()
     dt = time.perf_counter() - t0
@@ -165,36 +215,68 @@ def main():
     delta = np.array([float(s1[f].sum() - s0[f].sum()) for f in fields], np.float64)
     delta, dt_max, kernel_ms = reduce_run_statistics(delta, dt, kernel_ms, dist)   # the only collective (RCCL)
     stats_sum = dict(zip(fields, delta))
-    expected = float(args.batch) * args.steps * world
+    expected = float(global_batch) * args.steps * spl
     if int(stats_sum["total_steps"]) != int(expected):
         raise SystemExit(f"step accounting mismatch: {stats_sum['total_steps']} != {expected}")
 
     if rank == 0:
         value = expected / dt_max
         bytes_step, counters = algorithmic_bytes_per_step(stats_sum, wl["S"])
-        avg_launch_s = kernel_ms / 1e3 / max(launches, 1)
-        steps_per_launch_total = float(args.batch) * min(args.steps_per_launch, args.steps)
-        achieved = bytes_step * steps_per_launch_total / avg_launch_s / 1e9 if launches else 0.0
+        avg_launch_s = kernel_ms / 1e3 / args.steps
+        env_steps_per_launch = float(local_batch) * spl               # what ONE launch (on one GPU) processes
+        achieved = bytes_step * env_steps_per_launch / avg_launch_s / 1e9
+        pmc = pmc_summary(args.workload)
+        traffic = None
+        issue = None
+        if pmc:
+            hbm_b = pmc.get("hbm_bytes_per_env_step")
+            if hbm_b is not None:
+                traffic = hbm_b * env_steps_per_launch
+            valu = pmc.get("valu_per_env_step")
+            if valu is not None:
+                rate = valu * (float(local_batch) * spl / avg_launch_s)
+                issue = {"bound": "valu-issue", "valu_wave_insts_per_env_step": valu,
+                         "salu_wave_insts_per_env_step": pmc.get("salu_per_env_step"),
+                         "lds_wave_insts_per_env_step": pmc.get("lds_per_env_step"),
+                         "smem_wave_insts_per_env_step": pmc.get("smem_per_env_step"),
+                         "vmem_wave_insts_per_env_step": pmc.get("vmem_per_env_step"),
+                         "valu_busy_frac": pmc.get("valu_busy_frac"), "wait_any_frac": pmc.get("wait_any_frac"),
+                         "achieved": rate, "peak": VALU_ISSUE_PEAK, "unit": "VALU wave-insts/s",
+                         "frac": rate / VALU_ISSUE_PEAK,
+                         "source": pmc.get("source"), "note": "instruction counts per env-step from the tracked rocprofv3 "
+                         "--pmc passes (separate runs); rate = counts x the env-step rate measured live in this run"}
         out = {
             "metric": "env-steps/s (requests/s), QRMSA NSFNET-320 batch=65k, 1/2/4/8 GPU",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt_max * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt_max * 1e3 / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"QRMSA {args.workload}: {tables.name} {tables.n_nodes}n/{tables.n_links}e, "
                                    f"S={wl['S']}, k=5, 6 modulations, load {wl['load']} Erlang, discrete bit rates "
                                    f"{wl['bit_rates']}, episode_length 1000 with auto-reset, fused first-fit policy+step",
-                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "steps_per_launch": args.steps_per_launch, "parallelism": f"replica-sharded x{world}"},
+                       "batch_per_gpu": local_batch, "global_batch": global_batch,
+                       "steps_per_launch": spl, "env_steps_per_bench_step": float(global_batch) * spl,
+                       "fill_env_steps_per_replica_untimed": (fill_launches + args.warmup) * spl,
+                       "parallelism": f"replica-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_run<uniform_alpha,rec32,waves> (csrc/ongym_hip.hip)", "avg_launch_ms": avg_launch_s * 1e3,
-                         "algorithmic_bytes_per_env_step": bytes_step, "env_steps_per_launch": steps_per_launch_total,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_note": ("HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) per env-step from the "
+                                          "tracked PMC passes x env-steps per launch; state is LDS-resident for a whole "
+                                          "launch, so real traffic is far BELOW the algorithmic bytes and the HBM bound "
+                                          "does not bind: see `issue`") if traffic is not None else None,
+                         "kernel": "k_run<uniform_alpha,codec,waves,first_fit> (csrc/ongym_hip.hip)",
+                         "avg_launch_ms": avg_launch_s * 1e3,
+                         "algorithmic_bytes_per_env_step": bytes_step, "env_steps_per_launch": env_steps_per_launch,
                          **counters},
+            "issue": issue,
             "blocking_rate": 1.0 - stats_sum["total_accepted"] / stats_sum["total_steps"],
         }
+        # the timed state must be the loaded network, whatever the CLI said
+        out["steady_state"] = bool(counters["mean_active_services"] >= 0.4 * wl["load"])
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(tables, wl)
+            out["cpu_baseline"] = cpu_baseline(tables, wl, args.workload)
         print(json.dumps(out), flush=True)
+        if not out["steady_state"]:
+            print("bench.py: mean active services far below the offered load: not the stated workload", file=sys.stderr)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -210,6 +210,11 @@ void ongym_destroy(ongym_env *env);
 /* Request source A — device generator: replica r draws from the counter-based stream (seed, r) defined in
  * ongym_traffic.h.  Stands in for `self.rng = random.Random()` (qrmsa.pyx:241; unseeded in the reference, quirk Q2). */
 int ongym_seed(ongym_env *env, uint64_t seed);
+/* The same with a replica offset: local replica r draws stream (seed, replica_base + r).  A batch sharded over several
+ * environments / GPUs (shard k owning the global replicas [base_k, base_k + batch_k)) then simulates exactly the
+ * replicas of the unsharded batch — the fan-out of graph_load.py:361-363 (one simulation per Pool task) with
+ * reproducible streams.  ongym_seed(env, seed) == ongym_seed_base(env, seed, 0). */
+int ongym_seed_base(ongym_env *env, uint64_t seed, uint64_t replica_base);
 /* Request source B — trace replay: reqs[r*n_per_replica + i] is the i-th request replica r will draw.
  * Used for parity against captured reference traces (each _next_service call consumes one entry). */
 int ongym_set_requests(ongym_env *env, const ongym_request *reqs, int64_t n_per_replica);

@@ -129,10 +129,10 @@ __global__ __launch_bounds__(64) void k_observe(const Params *__restrict__ Pp, f
     observe_env<R32>(c, Fx, Vw, xlist, needx, obs + (size_t)c.replica * obs_dim, mask + (size_t)c.replica * nact);
 }
 
-__global__ void k_seed(Params P, uint64_t seed) {
+__global__ void k_seed(Params P, uint64_t seed, uint64_t replica_base) {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= P.batch) return;
-    P.env[r].rng_key = ongym_stream_key(seed, (uint64_t)r);
+    P.env[r].rng_key = ongym_stream_key(seed, replica_base + (uint64_t)r);
     P.env[r].req_index = 0;
 }
 
@@ -652,14 +652,16 @@ double ongym_last_kernel_ms(ongym_env *env) {
     return (double)ms;
 }
 
-int ongym_seed(ongym_env *env, uint64_t seed) {
+int ongym_seed(ongym_env *env, uint64_t seed) { return ongym_seed_base(env, seed, 0); }
+
+int ongym_seed_base(ongym_env *env, uint64_t seed, uint64_t replica_base) {
     if (!env) return ONGYM_E_ARG;
     HIP_TRY(env, hipSetDevice(env->cfg.device));
     env->P.req_mode = kReqRng;
     env->has_source = true;
     { int rc = push_params(env); if (rc) return rc; }
     int threads = 256, blocks = (env->P.batch + threads - 1) / threads;
-    hipLaunchKernelGGL(k_seed, dim3(blocks), dim3(threads), 0, env->stream, env->P, seed);
+    hipLaunchKernelGGL(k_seed, dim3(blocks), dim3(threads), 0, env->stream, env->P, seed, replica_base);
     HIP_TRY(env, hipGetLastError());
     return ONGYM_OK;
 }

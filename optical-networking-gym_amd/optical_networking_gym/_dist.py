@@ -22,9 +22,17 @@ def init_process_group(backend: str = "nccl", local_rank: int = 0):
     return dist
 
 
-def rank_seed(base_seed: int, rank: int) -> int:
-    """Seed of a rank's request streams: replica r of rank k draws stream (rank_seed, r)."""
-    return int(base_seed) + 1000003 * int(rank)
+def shard_bounds(global_batch: int, rank: int, world: int):
+    """(first global replica, replica count) of `rank` when `global_batch` independent replicas are dealt to `world`
+    ranks in contiguous slices (the first `global_batch % world` ranks take one more).  With
+    `env.seed(seed, replica_base=first)` replica r of the rank draws stream (seed, first + r): a sharded run simulates
+    exactly the replicas of the unsharded one, whatever the world size."""
+    global_batch, rank, world = int(global_batch), int(rank), int(world)
+    if not 0 <= rank < world or global_batch < world:
+        raise ValueError("need 0 <= rank < world <= global_batch")
+    q, rem = divmod(global_batch, world)
+    first = rank * q + min(rank, rem)
+    return first, q + (1 if rank < rem else 0)
 
 
 def reduce_run_statistics(delta: np.ndarray, dt: float, kernel_ms: float, dist=None, device: str = "cuda"):

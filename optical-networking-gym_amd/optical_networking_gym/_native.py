@@ -181,6 +181,7 @@ def _declare(lib):
     lib.ongym_destroy.argtypes = [vp]
     lib.ongym_destroy.restype = None
     lib.ongym_seed.argtypes = [vp, C.c_uint64]
+    lib.ongym_seed_base.argtypes = [vp, C.c_uint64, C.c_uint64]
     lib.ongym_set_requests.argtypes = [vp, vp, C.c_int64]
     lib.ongym_reset.argtypes = [vp, vp]
     lib.ongym_step_policy.argtypes = [vp, C.c_int32, C.c_int32, vp]
@@ -204,7 +205,7 @@ def _declare(lib):
     lib.ongym_last_error.restype = C.c_char_p
     lib.ongym_abi_version.argtypes = []
     lib.ongym_sizeof.argtypes = [C.c_int32]
-    for name in ("ongym_create", "ongym_seed", "ongym_set_requests", "ongym_reset", "ongym_step_policy",
+    for name in ("ongym_create", "ongym_seed", "ongym_seed_base", "ongym_set_requests", "ongym_reset", "ongym_step_policy",
                  "ongym_step_actions", "ongym_policy_actions", "ongym_observe", "ongym_query_available", "ongym_query_gsnr", "ongym_query_gsnr_many", "ongym_query_moves",
                  "ongym_query_grid", "ongym_query_services", "ongym_query_request", "ongym_stats_get", "ongym_sync",
                  "ongym_abi_version", "ongym_sizeof", "ongym_query_candidates", "ongym_query_path_free", "ongym_observe"):
@@ -212,7 +213,7 @@ def _declare(lib):
 
 
 EXPORTED_SYMBOLS = (
-    "ongym_create", "ongym_destroy", "ongym_seed", "ongym_set_requests", "ongym_reset", "ongym_step_policy",
+    "ongym_create", "ongym_destroy", "ongym_seed", "ongym_seed_base", "ongym_set_requests", "ongym_reset", "ongym_step_policy",
     "ongym_step_actions", "ongym_policy_actions", "ongym_observe", "ongym_query_available", "ongym_query_gsnr", "ongym_query_gsnr_many", "ongym_query_moves", "ongym_query_grid",
     "ongym_query_services", "ongym_query_request", "ongym_query_candidates", "ongym_query_path_free",
     "ongym_stats_get", "ongym_sync", "ongym_last_kernel_ms",

@@ -84,9 +84,11 @@ class BatchedQRMSAEnv:
         return self.holder.reject_action + 1
 
     # ---- request sources -----------------------------------------------------------------------------------------
-    def seed(self, seed: int):
-        """Device traffic generator; replica r uses stream (seed, r) of include/ongym_traffic.h."""
-        self._check(self.lib.ongym_seed(self._h, C.c_uint64(seed)), "ongym_seed")
+    def seed(self, seed: int, replica_base: int = 0):
+        """Device traffic generator; local replica r uses stream (seed, replica_base + r) of include/ongym_traffic.h.
+        `replica_base` = index of this environment's first replica in a batch sharded over several environments."""
+        self.replica_base = int(replica_base)
+        self._check(self.lib.ongym_seed_base(self._h, C.c_uint64(seed), C.c_uint64(replica_base)), "ongym_seed_base")
 
     def set_requests(self, requests: np.ndarray):
         """Trace replay: `requests` is a REQUEST_DTYPE array [batch, n] (or [n] for batch 1)."""

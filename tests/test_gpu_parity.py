@@ -185,6 +185,62 @@ def test_random_traffic_vs_oracle(topo, S, load, steps):
         assert a.tobytes() == b.tobytes()
 
 
+def test_sharded_batch_equals_unsharded_bit_exact():
+    """A batch split over two environments with replica bases 0 and B/2 (what two ranks of bench.py / a sharded sweep
+    own, `shard_bounds`) reproduces the single environment of B replicas bit for bit: per-replica statistics, grids and
+    step records.  SURVEY §4 item (4): sharded == unsharded; graph_load.py:361-363 fans out the same way."""
+    from optical_networking_gym._dist import shard_bounds
+    tb = golden_tables("nsfnet")
+    B, steps = 512, 1100
+    kw = dict(tables=tb, modulations=jocn_modulations(), num_spectrum_resources=320, capacity=448, load=300,
+              bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), episode_length=1000)
+    whole = BatchedQRMSAEnv(batch_size=B, **kw); whole.seed(5); whole.reset()
+    rec_whole = whole.step_policy(steps)
+    st_whole = whole.stats()
+    parts, recs = [], []
+    for rank in range(2):
+        base, n = shard_bounds(B, rank, 2)
+        e = BatchedQRMSAEnv(batch_size=n, **kw); e.seed(5, replica_base=base); e.reset()
+        recs.append(e.step_policy(steps))
+        parts.append(e)
+    st_parts = np.concatenate([e.stats() for e in parts])
+    assert st_parts.tobytes() == st_whole.tobytes()
+    assert np.concatenate(recs, axis=1).tobytes() == rec_whole.tobytes()
+    for r in (0, B // 2 - 1, B // 2, B - 1):
+        e, lr = (parts[0], r) if r < B // 2 else (parts[1], r - B // 2)
+        np.testing.assert_array_equal(e.grid(lr), whole.grid(r))
+    # and the reduction the ranks do (sum of the per-rank sums) equals the unsharded sum
+    for f in ("total_steps", "total_accepted", "total_gn_evals", "total_interferer_terms", "total_active_sum"):
+        assert sum(int(e.stats()[f].sum()) for e in parts) == int(st_whole[f].sum())
+
+
+def test_device_generator_continuous_bit_rates_vs_oracle():
+    """draw_next's randint branch (bit_rate_selection="continuous", qrmsa.pyx:1088-1089) on the DEVICE generator against
+    the oracle on the same (seed, replica) streams — slot counts then come from the ceil of get_number_slots
+    (qrmsa.pyx:1198-1205) instead of the discrete table."""
+    B, steps = 32, 1200
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=320, batch=B, capacity=1024, episode_length=1000,
+              auto_reset=True, load=700, bit_rate_selection="continuous", bit_rate_lower_bound=25,
+              bit_rate_higher_bound=400, margin=0.5)
+    holder = nat.ConfigHolder(golden_tables("nsfnet"), **kw)
+    want, oracles = run_oracle_batch(holder, 99, steps, B)
+    ekw = dict(kw); ekw.pop("batch")
+    env = BatchedQRMSAEnv(tables=golden_tables("nsfnet"), batch_size=B, **ekw)
+    env.seed(99)
+    env.reset()
+    got = env.step_policy(steps)
+    assert_records_equal(got, want, "continuous")
+    assert len(np.unique(got["nslots"][got["accepted"] == 1])) > 10      # really a continuum of slot counts
+    st = env.stats()
+    for r in (0, B - 1):
+        o = oracles[r].stats()
+        for f in ("services_accepted", "bit_rate_requested", "bit_rate_provisioned", "episode_bit_rate_provisioned",
+                  "rejected", "current_time", "active"):
+            assert st[r][f] == o[f], (r, f)
+        assert env.request(r).tobytes() == oracles[r].request().tobytes()
+        np.testing.assert_array_equal(env.grid(r), oracles[r].grid())
+
+
 def test_nonuniform_attenuation_vs_oracle():
     """per-link alpha (template path UNIFORM_ALPHA=false)."""
     import copy

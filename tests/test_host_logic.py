@@ -159,16 +159,17 @@ _WORKER = r'''
 import os, sys, json
 sys.path[:0] = [%r, %r]
 import numpy as np, torch, torch.distributed as dist
-from optical_networking_gym._dist import init_process_group, rank_seed, reduce_run_statistics
+from optical_networking_gym._dist import init_process_group, shard_bounds, reduce_run_statistics
 from common import holder_for, load_traj
 from oracle_lib import OracleEnv
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 init_process_group("gloo")
 meta, _ = load_traj("traj_nsfnet320")
-h = holder_for(meta, batch=2)
+h = holder_for(meta, batch=5)
 steps = 0; acc = 0
-for r in range(2):                       # each rank owns 2 replicas; the oracle stands in for the GPU engine on CPU
-    o = OracleEnv(h, replica=r); o.seed(rank_seed(7, rank)); o.reset()
+base, n = shard_bounds(5, rank, 2)        # 5 global replicas over 2 ranks (3 + 2); the oracle stands in for the GPU engine
+for r in range(base, base + n):          # global replica index = stream index, as env.seed(seed, replica_base=base) does
+    o = OracleEnv(h, replica=r); o.seed(7); o.reset()
     rec = o.run_first_fit(150); steps += len(rec); acc += int(rec["accepted"].sum())
 delta, dt_max, k_ms = reduce_run_statistics(np.array([steps, acc], np.float64), 1.0 + rank, 10.0 * (rank + 1), dist, device="cpu")
 if rank == 0:
@@ -186,15 +187,16 @@ def test_two_rank_statistics_reduction_gloo(tmp_path):
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     got = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    # single-process ground truth
-    from optical_networking_gym._dist import rank_seed
+    # ground truth: the UNSHARDED run of the same 5 replicas in one process — sharded == unsharded, exactly
+    from optical_networking_gym._dist import shard_bounds
+    assert [shard_bounds(5, k, 2) for k in range(2)] == [(0, 3), (3, 2)]
+    assert [shard_bounds(65536, k, 8) for k in (0, 7)] == [(0, 8192), (57344, 8192)]
     meta, _ = load_traj("traj_nsfnet320")
-    h = holder_for(meta, batch=2)
+    h = holder_for(meta, batch=5)
     steps = acc = 0
-    for rank in range(2):
-        for r in range(2):
-            o = OracleEnv(h, replica=r); o.seed(rank_seed(7, rank)); o.reset()
-            rec = o.run_first_fit(150); steps += len(rec); acc += int(rec["accepted"].sum())
+    for r in range(5):
+        o = OracleEnv(h, replica=r); o.seed(7); o.reset()
+        rec = o.run_first_fit(150); steps += len(rec); acc += int(rec["accepted"].sum())
     assert got["delta"] == [float(steps), float(acc)]
     assert got["dt_max"] == 2.0 and got["k_ms"] == 20.0
 
