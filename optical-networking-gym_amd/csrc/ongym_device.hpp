@@ -86,6 +86,9 @@ struct Params {
     const double2 *pair_tab;        // [tab_nmax][2S+1] (asinh difference, Bk/|df|) by (interferer slots, centre distance in
                                     //  half slots), uniform alpha only; NULL = always compute
     int tab_nmax, tab_stride;
+    // lean first-fit kernel (ongym_fast.hpp); NULL when the configuration is not eligible
+    const void *path_rec;           // PathRec [P]
+    const double *pair_tab2k;       // the pair table with a row pitch of 2048 entries: [tab_nmax][2048][2]
     const double *bit_rates, *bit_rate_cum, *node_cum;
     const double *path_len_norm;    // [P] observation(): (length - min link) / (max link - min link)
     double max_bit_rate;

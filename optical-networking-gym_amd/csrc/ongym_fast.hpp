@@ -1,0 +1,641 @@
+// ongym_fast.hpp — the lean fused first-fit kernel (k_fast): same path and same results as k_run<…, FIRST_FIT>, built around
+// ISSUE-SLOT economy.  tools/ubench/issue_rates.hip measured on MI355X (cycles per wave-instruction per SIMD, >= 2 waves):
+// 32-bit VALU 2.5, fp64 / 64-bit shift / DPP mov / v_readlane / v_alignbit 4.2, SALU 4.3, ds_read_b32 ~9.  The round-1
+// kernel spent 726 VALU + 625 SALU per request; at 5 waves/SIMD both pipes were ~2/3 busy, i.e. it was issue-bound on
+// both.  What this kernel does differently (reference semantics unchanged: envs/qrmsa.pyx:838-1122,
+// heuristics/heuristics.py:923-966, core/osnr.pyx:21-142):
+//   * requests are drawn 64 at a time (lane i = request index base+i of the same counter-based stream,
+//     include/ongym_traffic.h) and kept in three VGPRs; a step pops one with v_readlane.  The float32 clock chain stays
+//     serial (one v_add_f32 per request).
+//   * no DevEnv in LDS and no lane-0 read-modify-write chains: wave-uniform counters are plain (scalar) variables, the
+//     per-modulation / per-bit-rate histograms one lane-distributed VGPR (v_cmp + v_addc); everything is folded into
+//     DevEnv in memory at the end of the launch and around the (rare) terminal step.
+//   * the slot bitmap is handled as 32-bit words (lane w = word w): a run-AND step is DPP wave_shl:1 + v_alignbit_b32 +
+//     v_and_b32; bits are set / cleared by ds_or_b32 / ds_and_b32 with EXEC = the path's link mask (lane l = link l).
+//   * per (request, path) one fp64 FMA + compare over lanes (lane 8*bitrate + m = modulation m) removes every modulation
+//     whose ASE + self-channel lower bound already fails at slot 0 (exact: the bound only grows with the slot index, and
+//     no interferer term is negative — Params.ase_shortcut); the modulation loop walks the surviving bits.  The blocking
+//     FLAGS of a rejected request (1 % of the steps) are recomputed exactly by a second, plain pass.
+//   * the GN model caches the candidate path's interferers in registers once (centre, table row, link weights summed,
+//     Phi folded in), so each further modulation of the same path costs |c - c_k|, one 16-byte table gather and two
+//     fp64 FMAs per interferer; the acceptance test runs lane-parallel against per-lane limits (no readlane of doubles).
+//   * records are 8 bytes in LDS (link mask | centre, modulation, slots-1, path) + the float32 release time; unused
+//     entries are neutral (mask 0, release +inf), so no scan needs a bounds test.
+// The state in HBM is the generic kernels' (same arrays, same record codec), converted on load / store: every other entry
+// point keeps working on the same environment, and a launch may be split anywhere.
+//
+// Eligibility (checked on the host, fast_eligible): first-fit policy-step mode, device request generator, discrete bit
+// rates (<= 8, integer-valued), uniform attenuation, ase_shortcut, no defragmentation / disruptions, n_links <= 52,
+// n_nodes <= 64, max_hops <= 16, every slot count of the traffic table <= min(512, tab_nmax), 2S+1 < 2048.
+#pragma once
+#include "ongym_device.hpp"
+
+namespace ongym {
+
+constexpr int kTabPitch = 2048;      // pair-table row pitch (2S+1 <= 2047)
+
+// ---- path record (8 dwords, 32-byte aligned: one s_load_dwordx8) -------------------------------------------------------
+struct PathRec {
+    uint32_t hops, mask_lo, mask_hi, id;   // mask = links of the path (bit l = link l), n_links <= 52
+    double ase, w1;                        // path_ase[id], path_w1[id]
+};
+static_assert(sizeof(PathRec) == 32, "PathRec must be 32 bytes");
+__device__ __forceinline__ PathRec load_path_rec(const __attribute__((address_space(4))) PathRec *t, int path) {
+    PathRec r;      // field by field: the constant address space has no copy constructor; still one s_load_dwordx8
+    r.hops = t[path].hops; r.mask_lo = t[path].mask_lo; r.mask_hi = t[path].mask_hi; r.id = t[path].id;
+    r.ase = t[path].ase; r.w1 = t[path].w1;
+    return r;
+}
+struct TabPair { double x, y; };
+__device__ __forceinline__ TabPair load_pair(const char __attribute__((address_space(1))) *tab, uint32_t byte_off) {
+    const double __attribute__((address_space(1))) *p = (const double __attribute__((address_space(1))) *)(tab + (size_t)byte_off);
+    TabPair t;
+    t.x = p[0]; t.y = p[1];
+    return t;
+}
+
+// Read-only tables are addressed through the constant address space: a wave-uniform index then always becomes a scalar
+// load (the compiler cannot prove that the kernel's own global stores leave a plain global pointer's target alone).
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(4))) T *KC(const T *p) {
+    return (const __attribute__((address_space(4))) T *)p;
+}
+
+__host__ __device__ inline size_t fast_lds_bytes(int n_links, int row_words, int capacity, bool m64) {
+    size_t b = ((size_t)n_links * row_words * 8 + 15) & ~(size_t)15;   // occ  u32 [E][2W]
+    b += (size_t)n_links * 16 + 64;                                     // lw (w1,w2) [E] | phi [8]
+    b += (size_t)capacity * (8 + 4 + 2 + (m64 ? 4 : 0));                // rec {a,b} | rr | list | (a2)
+    return (b + 15) & ~(size_t)15;
+}
+
+__device__ __forceinline__ uint32_t rl(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+__device__ __forceinline__ float rlf(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+
+// word of lane+1 (0 for lane 63): DPP wave_shl:1
+__device__ __forceinline__ uint32_t next_word32(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xF, 0xF, true);
+}
+
+// run-AND on 32-bit words (see run_and): bit s of word w set iff slots [32w+s, 32w+s+m) are all free
+__device__ __forceinline__ uint32_t run_and32(uint32_t x, int &r, int m) {
+    while (r < m) {
+        const int s = min(r, m - r);
+        uint32_t y = x;
+        int t = s;
+        while (t >= 32) { y = next_word32(y); t -= 32; }      // whole-word part of the shift (slot counts > 32 only)
+        if (t) y = __builtin_amdgcn_alignbit(next_word32(y), y, t);
+        x &= y;
+        r += s;
+    }
+    return x;
+}
+
+__device__ __forceinline__ int first_set32(uint32_t x) {
+    const uint64_t bal = __ballot(x != 0);
+    if (!bal) return -1;
+    const int fl = __builtin_ctzll(bal);
+    return fl * 32 + __builtin_ctz(rl(x, fl));
+}
+
+// EXEC-masked LDS operations: the lanes of `mask` (lane l = link l) apply `val` to the word at `addr`.  One asm statement
+// each; EXEC is all ones before and after (the kernel's control flow is wave-uniform around every call site).
+// (s_and_saveexec keeps the caller's EXEC: two scalar instructions around the DS operation, no VALU compare.)
+__device__ __forceinline__ void lds_and_lanes(uint64_t mask, uint32_t addr, uint32_t val) {
+    uint64_t saved;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_and_b32 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "s"(mask), "v"(addr), "v"(val) : "memory", "scc");
+}
+__device__ __forceinline__ void lds_or_lanes(uint64_t mask, uint32_t addr, uint32_t val) {
+    uint64_t saved;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_or_b32 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "s"(mask), "v"(addr), "v"(val) : "memory", "scc");
+}
+__device__ __forceinline__ void lds_write_lane0(uint32_t addr64, uint64_t v64, uint32_t addr32, uint32_t v32) {
+    uint64_t saved;
+    asm volatile("s_and_saveexec_b64 %0, 1\n\tds_write_b64 %1, %2\n\tds_write_b32 %3, %4\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "v"(addr64), "v"(v64), "v"(addr32), "v"(v32) : "memory", "scc");
+}
+__device__ __forceinline__ void lds_write_lane0_b32(uint32_t addr32, uint32_t v32) {
+    uint64_t saved;
+    asm volatile("s_and_saveexec_b64 %0, 1\n\tds_write_b32 %1, %2\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "v"(addr32), "v"(v32) : "memory", "scc");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {   // byte address inside the workgroup's LDS
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)p;
+}
+__device__ __forceinline__ uint32_t word_mask32(int w, int lo, int hi) {     // bits [lo, hi) that fall into 32-bit word w
+    const int a = max(lo - 32 * w, 0), b = min(hi - 32 * w, 32);
+    if (b <= a) return 0u;
+    return (b - a == 32) ? ~0u : (((1u << (b - a)) - 1u) << a);
+}
+
+// record word b: centre 2*slot+n (11 bits) | modulation << 11 | (n-1) << 14 (9 bits) | path << 23 (9 bits)
+__device__ __forceinline__ uint32_t fast_pack_b(int slot, int n, int mod, int path) {
+    return (uint32_t)(2 * slot + n) | ((uint32_t)mod << 11) | ((uint32_t)(n - 1) << 14) | ((uint32_t)(path & 0x1FF) << 23);
+}
+
+template <bool M64, bool REC, int ENT>
+__device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step_rec *out, unsigned char *smem) {
+    ONGYM_NO_CONTRACT
+    const int lane = threadIdx.x, replica = blockIdx.x;
+    const int E = P.n_links, RW = P.row_words * 2, C = P.capacity, S = P.n_slots, M = P.n_mods, K = P.k_paths, N = P.n_nodes;
+    DevEnv *const ge = P.env + replica;
+
+    // ---- LDS carve-up ----
+    uint32_t *const occ = reinterpret_cast<uint32_t *>(smem);
+    size_t o = ((size_t)E * RW * 4 + 15) & ~(size_t)15;
+    double *const lw = reinterpret_cast<double *>(smem + o); o += (size_t)E * 16;
+    double *const phi = reinterpret_cast<double *>(smem + o); o += 64;
+    uint2 *const rec = reinterpret_cast<uint2 *>(smem + o); o += (size_t)C * 8;
+    float *const rr = reinterpret_cast<float *>(smem + o); o += (size_t)C * 4;
+    uint32_t *const a2 = reinterpret_cast<uint32_t *>(smem + o); if (M64) o += (size_t)C * 4;
+    uint16_t *const list = reinterpret_cast<uint16_t *>(smem + o);
+    const uint32_t occ_base = lds_addr(occ), rec_base = lds_addr(rec), rr_base = lds_addr(rr), a2_base = lds_addr(a2);
+    const uint32_t v_rowaddr = occ_base + (uint32_t)lane * (uint32_t)RW * 4u;    // lane l = link l: its bitmap row
+
+    // ---- load: constants, bitmap, records (generic codec -> lean codec) ----
+    for (int i = lane; i < E; i += kWave) { lw[2 * i] = G(P.link_w1)[i]; lw[2 * i + 1] = G(P.link_w2)[i]; }
+    if (lane < kMaxMods) phi[lane] = lane < M ? P.mod_phi53[lane] : 0.0;
+    {
+        const uint32_t *g = reinterpret_cast<const uint32_t *>(P.occ + (size_t)replica * E * P.row_words);
+        for (int i = lane; i < E * RW; i += kWave) occ[i] = g[i];
+    }
+    int active = uniform_i32(ge->st.active);
+    {
+        const size_t off = (size_t)replica * C;
+        for (int i = lane; i < C; i += kWave) {
+            uint2 ab = make_uint2(0u, 0u);
+            float r = INFINITY;
+            uint32_t hi = 0;
+            if (i < active) {
+                const uint32_t a = P.svc_a[off + i], b = P.svc_b[off + i];
+                r = P.svc_r[off + i];
+                int path, slot, n, mod;
+                if (P.rec32) { ab.x = a; slot = rec_slot<true>(a, b); n = rec_n<true>(a, b); mod = rec_mod<true>(a, b); path = rec_path<true>(a, b); }
+                else {
+                    slot = rec_slot<false>(a, b); n = rec_n<false>(a, b); mod = rec_mod<false>(a, b); path = rec_path<false>(a, b);
+                    const uint64_t m0 = G(P.path_mask)[2 * path];
+                    ab.x = (uint32_t)m0;
+                    hi = (uint32_t)(m0 >> 32) | ((uint32_t)(path >> 9) << 20);
+                }
+                ab.y = fast_pack_b(slot, n, mod, path);
+            }
+            rec[i] = ab; rr[i] = r;
+            if (M64) a2[i] = hi;
+        }
+    }
+
+    // ---- per-lane tables: lane q = 8*bit_rate_index + modulation ----
+    const double lp = uniform_f64(ge->launch_power), margin = uniform_f64(ge->margin);
+    const double rp0 = 1.0 / lp, lp2 = lp * lp;
+    const float mean_iat_f = uniform_f32(ge->mean_iat_f);
+    int t_n;
+    double t_nlic, t_selfa, t_lim, t_bw, t_h, t_pre_a, t_pre_b, t_lim_pf;
+    {
+        const int qb = lane >> 3, qm = lane & 7;
+        const bool valid = qb < P.n_bit_rates && qm < M;
+        const int at_ = qb * kMaxMods + qm;
+        t_n = valid ? G(P.nreq_tab)[at_] : 0;
+        t_nlic = valid ? G(P.req_coef)[2 * at_] * lp2 : 0.0;
+        t_selfa = valid ? G(P.req_coef)[2 * at_ + 1] : 0.0;
+        t_lim = pow(10.0, -(P.mod_thr[qm < M ? qm : 0] + margin) / 10.0);      // same expression as load_state
+        t_bw = P.slot_bw * t_n;
+        t_h = P.slot_bw * (t_n / 2.0);
+        // lower bound of 1/GSNR at slot 0 = ASE(slot 0) + self-channel NLI:  pre_a * path_ase + pre_b * path_w1
+        t_pre_a = (t_bw * (P.f0 + t_h)) * rp0;
+        t_pre_b = t_nlic * t_selfa;
+        t_lim_pf = (valid && t_n >= 1 && t_n <= S) ? t_lim * (1.0 + 2e-9) : -1.0;
+    }
+    const float t_br = lane < P.n_bit_rates ? (float)G(P.bit_rates)[lane] : 0.f;     // lane b = bit rate b
+
+    // ---- wave-uniform state from DevEnv ----
+    const uint64_t key = readlane_u64(ge->rng_key, 0);
+    uint64_t req_base = readlane_u64(ge->req_index, 0);        // ring lane i = request req_base + i
+    float v_at = uniform_f32((float)ge->st.current_time);  // current_time is always a float32 value ((double)at, qrmsa.pyx:1081)
+    int epp = uniform_i32((int)ge->st.episode_services_processed);
+    int eacc = uniform_i32((int)ge->st.episode_services_accepted), erej = uniform_i32((int)ge->st.rejected);
+    double base_req = uniform_f64(ge->st.bit_rate_requested), base_prov = uniform_f64(ge->st.bit_rate_provisioned);
+    double base_ereq = uniform_f64(ge->st.episode_bit_rate_requested), base_eprov = uniform_f64(ge->st.episode_bit_rate_provisioned);
+    double osnr_flushed = uniform_f64(ge->osnr_flushed);
+    double osnr_prod = uniform_f64(ge->osnr_prod > 0.0 ? ge->osnr_prod : 1.0);
+    int cnt = (lane >= 8 && lane < 16) ? (int)ge->st.episode_modulation_hist[lane - 8] : 0;
+    int lane_terms = 0;
+    // current request (drawn by whoever ran before: k_reset, k_run or a previous k_fast launch)
+    float cur_ht = uniform_f32(ge->cur_ht);
+    int cur_src = uniform_i32(ge->cur_src), cur_dst = uniform_i32(ge->cur_dst);
+    int cur_bi;
+    {
+        const float br = uniform_f32(ge->cur_br);
+        const uint64_t hit = __ballot(lane < P.n_bit_rates && t_br == br);
+        cur_bi = hit ? __builtin_ctzll(hit) : 0;
+    }
+    int cur_p0 = uniform_i32(KC(P.pair_paths)[(cur_src * N + cur_dst) * K]);
+    // launch deltas
+    int d_pops = 0, d_acc = 0, d_steps = 0, d_evals = 0, d_skips = 0, d_paths = 0, d_hops = 0, d_flags = 0, d_episodes = 0;
+    unsigned long long d_active_sum = 0;
+
+    float rq_iat, rq_ht;
+    uint32_t rq_pk;
+    int rq_pos = 0;
+    auto refill = [&]() {      // 64 requests: lane i evaluates ongym_draw_request for index req_base + i, minus the clock add
+        const uint64_t ctr = (req_base + (uint64_t)lane) * ONGYM_DRAWS_PER_REQUEST;
+        const double u0 = ongym_uniform(key, ctr + 0), u1 = ongym_uniform(key, ctr + 1), u2 = ongym_uniform(key, ctr + 2),
+                     u3 = ongym_uniform(key, ctr + 3), u4 = ongym_uniform(key, ctr + 4);
+        rq_iat = -ongym_logf_det(1.0 - u0) * mean_iat_f;          // ongym_expovariate_f
+        rq_ht = -ongym_logf_det(1.0 - u1) * P.mean_holding_f;
+        const double total = G(P.node_cum)[N - 1];
+        const double xs = u2 * total;
+        int src = 0;
+        for (int i = 0; i < N - 1; i++) src += (G(P.node_cum)[i] <= xs) ? 1 : 0;      // == ongym_bisect (cum is non-decreasing)
+        const double hi_s = G(P.node_cum)[src];
+        const double lo_s = src > 0 ? G(P.node_cum)[src - 1] : 0.0;
+        const double w_s = hi_s - lo_s;
+        double x = u3 * (total - w_s);
+        if (x >= lo_s) x += w_s;
+        int dst = 0;
+        for (int i = 0; i < N - 1; i++) dst += (G(P.node_cum)[i] <= x) ? 1 : 0;
+        if (dst == src) dst = (src + 1 < N) ? src + 1 : src - 1;
+        const int nb = P.n_bit_rates;
+        const double xb = u4 * G(P.bit_rate_cum)[nb - 1];
+        int bi = 0;
+        for (int i = 0; i < nb - 1; i++) bi += (G(P.bit_rate_cum)[i] <= xb) ? 1 : 0;
+        const int p0 = G(P.pair_paths)[(src * N + dst) * K];
+        rq_pk = (uint32_t)src | ((uint32_t)dst << 6) | ((uint32_t)bi << 12) | ((uint32_t)(p0 + 1) << 15);
+        rq_pos = 0;
+    };
+    refill();
+    wave_sync();
+
+    // ---- fold the launch state into DevEnv (memory); idempotent: deltas are zeroed once added ----
+    auto store_env = [&]() {
+        int terms = lane_terms;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) terms += __shfl_xor(terms, m);
+        lane_terms = 0;
+        int hist[8], nreq_b[8], nacc_b[8];
+        float brs[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { hist[i] = (int)rl((uint32_t)cnt, 8 + i); nreq_b[i] = (int)rl((uint32_t)cnt, 16 + i); nacc_b[i] = (int)rl((uint32_t)cnt, 24 + i); brs[i] = rlf(t_br, i); }
+        if (lane == 0) {
+            ongym_stats &s = ge->st;
+            ge->req_index = req_base + (uint64_t)rq_pos;
+            s.current_time = (double)v_at;
+            ge->cur_at = v_at; ge->cur_ht = cur_ht; ge->cur_br = brs[cur_bi]; ge->cur_src = cur_src; ge->cur_dst = cur_dst;
+            ge->cur_id = epp - 1; ge->have_request = 1;
+            s.services_processed += d_pops; s.episode_services_processed = epp;
+            s.services_accepted += d_acc; s.total_accepted += d_acc;
+            s.episode_services_accepted = eacc; s.rejected = erej;
+            double rq = 0.0, pv = 0.0;       // exact: bit rates are integer-valued (eligibility), counts are small integers
+            for (int i = 0; i < 8; i++) { s.episode_modulation_hist[i] = hist[i]; rq += (double)nreq_b[i] * (double)brs[i]; pv += (double)nacc_b[i] * (double)brs[i]; }
+            s.bit_rate_requested = base_req + rq; s.episode_bit_rate_requested = base_ereq + rq;
+            s.bit_rate_provisioned = base_prov + pv; s.episode_bit_rate_provisioned = base_eprov + pv;
+            s.episode_osnr_sum = osnr_flushed + (osnr_prod != 1.0 ? -10.0 * log10(osnr_prod) : 0.0);
+            ge->osnr_flushed = osnr_flushed; ge->osnr_prod = osnr_prod;
+            s.episodes_completed += d_episodes;
+            s.total_steps += d_steps; s.total_gn_evals += d_evals; s.total_gn_shortcuts += d_skips;
+            s.total_interferer_terms += terms; s.total_paths_tried += d_paths; s.total_path_hops += d_hops;
+            s.total_active_sum += (long long)d_active_sum;
+            s.active = active; s.flags |= d_flags;
+        }
+        d_pops = d_acc = d_steps = d_evals = d_skips = d_paths = d_hops = d_flags = d_episodes = 0;
+        d_active_sum = 0;
+    };
+
+    // next request: pop the ring, advance the float32 clock (envs/qrmsa.pyx:1079-1111)
+    auto pop_request = [&]() {
+        if (rq_pos == kWave) { req_base += kWave; refill(); }
+        const uint32_t pk = rl(rq_pk, rq_pos);
+        v_at = v_at + rlf(rq_iat, rq_pos);              // at = float32(current_time + expovariate)
+        cur_ht = rlf(rq_ht, rq_pos);
+        rq_pos++;
+        cur_src = pk & 63; cur_dst = (pk >> 6) & 63; cur_bi = (pk >> 12) & 7; cur_p0 = (int)(pk >> 15) - 1;
+        epp++; d_pops++;
+        cnt += (lane == 16 + cur_bi) ? 1 : 0;           // bit_rate_requested, by bit rate
+    };
+
+    // AND of the free bitmaps of a path's links, extended by the virtual free slot S (see path_free_ext); the links come
+    // from the path's mask (their order does not matter)
+    const int wl = min(lane, RW - 1);
+    auto path_and = [&](uint64_t links) -> uint32_t {
+        uint32_t x = lane < RW ? ~0u : 0u;
+        while (links) {
+            const int l = __builtin_ctzll(links);
+            links &= links - 1;
+            x &= occ[l * RW + wl];
+        }
+        if (lane == (S >> 5)) x |= 1u << (S & 31);
+        return x;
+    };
+
+    // set (free) or clear the slots [lo, hi) on the links of `mask`
+    auto mark = [&](uint64_t mask, int lo, int hi, bool free_) {
+        for (int w = lo >> 5; w <= (hi - 1) >> 5; w++) {
+            const uint32_t m = word_mask32(w, lo, hi);
+            if (free_) lds_or_lanes(mask, v_rowaddr + (uint32_t)w * 4u, m);
+            else lds_and_lanes(mask, v_rowaddr + (uint32_t)w * 4u, ~m);
+        }
+    };
+
+    const char __attribute__((address_space(1))) *const tab = (const char __attribute__((address_space(1))) *)P.pair_tab2k;
+    const __attribute__((address_space(4))) PathRec *const path_recs = KC(reinterpret_cast<const PathRec *>(P.path_rec));
+
+    if (!uniform_i32(ge->have_request)) {            // never reset: every step is a no-op (same as k_run)
+        if (lane == 0) {
+            ge->st.flags |= ONGYM_F_NO_REQUEST;
+            if (REC) for (int it = 0; it < nsteps; ++it) {
+                ongym_step_rec r;
+                memset(&r, 0, sizeof(r));
+                r.action = -1; r.route = r.modulation = r.slot = -1; r.flags = ONGYM_F_NO_REQUEST; r.active = active;
+                out[(size_t)it * P.batch + replica] = r;
+            }
+        }
+        return;
+    }
+
+    for (int it = 0; it < nsteps; ++it) {
+        // ================= policy: heuristic_shortest_available_path_first_fit_best_modulation =========================
+        int ch_k = -1, ch_m = 0, ch_slot = 0, ch_n = 0, ch_path = -1;
+        uint64_t ch_mask = 0;
+        double ch_acc = 0.0, ch_ase = 0.0, ch_nli = 0.0;
+        for (int k = 0; k < K; k++) {
+            const int path = k == 0 ? cur_p0 : uniform_i32(KC(P.pair_paths)[(cur_src * N + cur_dst) * K + k]);
+            if (path < 0) break;
+            const PathRec pr = load_path_rec(path_recs, path);
+            d_paths++; d_hops += pr.hops;
+            // modulations whose lower bound at slot 0 already fails cannot pass at any slot
+            const double lb = t_pre_a * pr.ase + t_pre_b * pr.w1;
+            uint32_t feas = (uint32_t)(__ballot(lb < t_lim_pf) >> (8 * cur_bi)) & 0xFFu;
+            d_skips += M - __popc(feas);            // modulations settled by the bound (statistics only)
+            if (!feas) continue;
+            const uint64_t pmask = (uint64_t)pr.mask_lo | ((uint64_t)(pr.mask_hi & 0xFFFFFu) << 32);
+            uint32_t runs = path_and(pmask);
+            int r = 1, L = -1;
+            uint32_t e_c2k[ENT], e_key4[ENT];
+            double e_w1[ENT], e_pw2[ENT];
+            int e_terms = 0;
+            while (feas) {
+                const int m = 31 - __builtin_clz(feas);            // best modulation first
+                feas &= ~(1u << m);
+                const int q = 8 * cur_bi + m;
+                const int n = (int)rl((uint32_t)t_n, q);
+                if (n + 1 < r) { runs = path_and(pmask); r = 1; }     // slot counts normally grow as the modulation index falls
+                runs = run_and32(runs, r, n + 1);
+                const int first = first_set32(runs);
+                if (first < 0) continue;
+                if (L < 0) {
+                    // ---- pass 1: interferers of this path -> LDS list -> registers (first 64*ENT of them)
+                    L = 0;
+                    for (int base = 0; base < active; base += 2 * kWave) {
+                        const int i0 = base + lane, i1 = i0 + kWave;
+                        bool ov0 = (rec[i0].x & pr.mask_lo) != 0, ov1 = i1 < C && (rec[i1].x & pr.mask_lo) != 0;
+                        if (M64) { ov0 |= (a2[i0] & pr.mask_hi & 0xFFFFFu) != 0; ov1 |= i1 < C && (a2[i1] & pr.mask_hi & 0xFFFFFu) != 0; }
+                        const uint64_t bal0 = __ballot(ov0), bal1 = __ballot(ov1);
+                        const int n0 = __popcll((unsigned long long)bal0);
+                        const int p0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal0, 0));
+                        const int p1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal1, 0));
+                        if (ov0) list[L + p0] = (uint16_t)i0;
+                        if (ov1) list[L + n0 + p1] = (uint16_t)i1;
+                        L += n0 + __popcll((unsigned long long)bal1);
+                    }
+                    wave_sync();
+#pragma unroll
+                    for (int e = 0; e < ENT; e++) {
+                        const int j = lane + kWave * e;
+                        e_c2k[e] = 0; e_key4[e] = 0; e_w1[e] = 0.0; e_pw2[e] = 0.0;
+                        if (j < L) {
+                            const int idx = list[j];
+                            const uint2 ab = rec[idx];
+                            e_c2k[e] = ab.y & 0x7FFu;
+                            e_key4[e] = ((ab.y >> 14) & 0x1FFu) << 15;       // (n-1) * kTabPitch entries * 16 bytes
+                            uint32_t mm = ab.x & pr.mask_lo;
+                            double w1 = 0.0, w2 = 0.0;
+                            e_terms += __popc(mm);
+                            while (mm) { const int l = __ffs(mm) - 1; mm &= mm - 1; w1 += lw[2 * l]; w2 += lw[2 * l + 1]; }
+                            if (M64) {
+                                uint32_t mh = a2[idx] & pr.mask_hi & 0xFFFFFu;
+                                e_terms += __popc(mh);
+                                while (mh) { const int l = 32 + __ffs(mh) - 1; mh &= mh - 1; w1 += lw[2 * l]; w2 += lw[2 * l + 1]; }
+                            }
+                            e_w1[e] = w1;
+                            e_pw2[e] = phi[(ab.y >> 11) & 7u] * w2;
+                        }
+                    }
+                }
+                // ---- pass 2: 1/GSNR of (path, first, n) ----
+                const uint32_t c2 = (uint32_t)(2 * first + n);
+                double part = 0.0;
+                {
+                    TabPair t[ENT];
+#pragma unroll
+                    for (int e = 0; e < ENT; e++) {
+                        const uint32_t adi = __builtin_amdgcn_sad_u16(e_c2k[e], c2, 0);       // |c2k - c2|, both < 2^11
+                        t[e] = load_pair(tab, e_key4[e] | (adi << 4));
+                    }
+#pragma unroll
+                    for (int e = 0; e < ENT; e++) part += t[e].x * e_w1[e] - t[e].y * e_pw2[e];
+                }
+                lane_terms += e_terms;
+                for (int base = kWave * ENT; base < L; base += kWave) {       // interferers beyond the register cache
+                    const int j = base + lane;
+                    if (j < L) {
+                        const int idx = list[j];
+                        const uint2 ab = rec[idx];
+                        const uint32_t adi = __builtin_amdgcn_sad_u16(ab.y & 0x7FFu, c2, 0);
+                        const TabPair t = load_pair(tab, (((ab.y >> 14) & 0x1FFu) << 15) | (adi << 4));
+                        uint32_t mm = ab.x & pr.mask_lo;
+                        double w1 = 0.0, w2 = 0.0;
+                        lane_terms += __popc(mm);
+                        while (mm) { const int l = __ffs(mm) - 1; mm &= mm - 1; w1 += lw[2 * l]; w2 += lw[2 * l + 1]; }
+                        if (M64) {
+                            uint32_t mh = a2[idx] & pr.mask_hi & 0xFFFFFu;
+                            lane_terms += __popc(mh);
+                            while (mh) { const int l = 32 + __ffs(mh) - 1; mh &= mh - 1; w1 += lw[2 * l]; w2 += lw[2 * l + 1]; }
+                        }
+                        part += t.x * w1 - t.y * (phi[(ab.y >> 11) & 7u] * w2);
+                    }
+                }
+                d_evals++;
+                const double tot = wave_sum(part);
+                // every lane finishes the evaluation for ITS (bit rate, modulation); lane q is the one that counts
+                const double fc = P.f0 + (P.slot_bw * first) + t_h;                  // envs/qrmsa.pyx:901-905
+                const double g_nli = t_nlic * (tot + pr.w1 * t_selfa);
+                const double g_ase = (t_bw * fc * pr.ase) * rp0;
+                const double acc = g_ase + g_nli;
+                int ok;
+                {
+                    const uint64_t yes = __ballot(acc <= t_lim * (1.0 - 1e-9)), no = __ballot(acc >= t_lim * (1.0 + 1e-9));
+                    if ((yes >> q) & 1ull) ok = 1;
+                    else if ((no >> q) & 1ull) ok = 0;
+                    else {      // inside the 1e-9 band: the reference's own dB-domain expression (see qot_ok)
+                        const uint64_t db = __ballot(10.0 * log10(1.0 / acc) >= P.mod_thr[lane & 7] + margin);
+                        ok = (int)((db >> q) & 1ull);
+                    }
+                }
+                if (ok) {
+                    ch_k = k; ch_m = m; ch_slot = first; ch_n = n; ch_path = path;
+                    ch_mask = pmask;
+                    ch_acc = readlane_f64(acc, q);
+                    if (REC) { ch_ase = readlane_f64(g_ase, q); ch_nli = readlane_f64(g_nli, q); }
+                    break;
+                }
+            }
+            if (ch_k >= 0) break;
+        }
+
+        // ================= step (envs/qrmsa.pyx:838-1065) ==============================================================
+        int accepted = ch_k >= 0;
+        int rflags = 0;
+        if (accepted && active >= C) { accepted = 0; rflags |= ONGYM_F_OVERFLOW; d_flags |= ONGYM_F_OVERFLOW; }
+        if (accepted) {
+            // _provision_path (:1288-1325): n slots + one guard slot unless the allocation ends at S
+            int end = ch_slot + ch_n; if (end < S) end += 1;
+            mark(ch_mask, ch_slot, end, false);
+            const float rel = v_at + cur_ht;                  // float + float (:1329); compared as float32 (:1114-1115)
+            const uint32_t ra = (uint32_t)ch_mask, rb = fast_pack_b(ch_slot, ch_n, ch_m, ch_path);
+            lds_write_lane0(rec_base + (uint32_t)active * 8u, (uint64_t)ra | ((uint64_t)rb << 32), rr_base + (uint32_t)active * 4u, __float_as_uint(rel));
+            if (M64) lds_write_lane0_b32(a2_base + (uint32_t)active * 4u, (uint32_t)(ch_mask >> 32) | ((uint32_t)(ch_path >> 9) << 20));
+            active++;
+            eacc++; d_acc++;
+            cnt += (lane == 8 + ch_m || lane == 24 + cur_bi) ? 1 : 0;
+            osnr_prod *= ch_acc;
+            if (osnr_prod < 1e-250) { osnr_flushed += -10.0 * log10(osnr_prod); osnr_prod = 1.0; }
+        } else {
+            erej++;
+            if (ch_k < 0) {
+                // blocking flags of the heuristic's return tuple, exactly: a (path, modulation) pair without candidates sets
+                // blocked_resources, one with candidates clears it and sets blocked_osnr (none passed, or we would not be
+                // here).  Candidates shrink as the slot count grows, so only the smallest and, on the last path, the
+                // largest slot count matter.
+                int bres = 0, bosnr = 0;
+                int n_small = 0x7fffffff, n_big = 0, n_last = 0;
+                for (int m = M - 1; m >= 0; m--) {
+                    const int n = (int)rl((uint32_t)t_n, 8 * cur_bi + m);
+                    if (n <= 0) continue;
+                    n_small = min(n_small, n); n_big = max(n_big, n); n_last = n;
+                }
+                for (int k = 0; k < K && n_big > 0; k++) {
+                    const int path = uniform_i32(KC(P.pair_paths)[(cur_src * N + cur_dst) * K + k]);
+                    if (path < 0) break;
+                    const PathRec pr = load_path_rec(path_recs, path);
+                    const uint32_t x = path_and((uint64_t)pr.mask_lo | ((uint64_t)(pr.mask_hi & 0xFFFFFu) << 32));
+                    int r1 = 1;
+                    const bool any = first_set32(run_and32(x, r1, n_small + 1)) >= 0;
+                    if (any) { bosnr = 1; bres = 0; }
+                    // the LAST pair visited decides blocked_resources: modulation 0's slot count on this path
+                    int r2 = 1;
+                    const bool last_has = first_set32(run_and32(x, r2, n_last + 1)) >= 0;
+                    bres = last_has ? 0 : 1;
+                    (void)n_big;
+                }
+                rflags |= (bres ? ONGYM_F_BLOCKED_RESOURCES : 0) | (bosnr ? ONGYM_F_BLOCKED_OSNR : 0);
+            }
+        }
+        d_steps++;
+
+        ongym_step_rec *const recp = REC ? out + (size_t)it * P.batch + replica : nullptr;
+        if (REC) {
+            ongym_step_rec r;
+            r.action = K * M * S; r.route = -1; r.modulation = -1; r.slot = -1; r.nslots = 0;
+            r.accepted = 0; r.terminated = 0; r.retry = 0; r.flags = (uint8_t)rflags;
+            r.osnr = 0.0; r.ase = 0.0; r.nli = 0.0; r.reward = -6.0; r.active = 0;
+            if (accepted) {
+                r.action = ch_k * M * S + (M - 1 - ch_m) * S + ch_slot;      // get_action_index, heuristics.py:36-54
+                r.route = (int16_t)ch_k; r.modulation = (int16_t)ch_m; r.slot = (int16_t)ch_slot; r.nslots = (int16_t)ch_n;
+                r.accepted = 1; r.reward = 0.0;                                  // quirk Q1
+                r.osnr = -10.0 * log10(ch_ase + ch_nli); r.ase = -10.0 * log10(ch_ase); r.nli = -10.0 * log10(ch_nli);
+            } else if (ch_k >= 0) {     // overflow: the policy had chosen, the table is full
+                r.action = ch_k * M * S + (M - 1 - ch_m) * S + ch_slot;
+            }
+            if (lane == 0) *recp = r;
+        }
+
+        // the info dict of the terminal step is computed before the next request is drawn (:996-1060)
+        const bool term = (epp + 1 == P.episode_length);
+        if (term) {
+            osnr_flushed += (osnr_prod != 1.0) ? -10.0 * log10(osnr_prod) : 0.0; osnr_prod = 1.0;      // flush_osnr
+            store_env();
+            __threadfence_block();
+            if (lane == 0) {
+                const ongym_stats &s = ge->st;
+                ongym_stats &so = ge->st;
+                so.last_episode_processed = s.episode_services_processed; so.last_episode_accepted = s.episode_services_accepted;
+                so.last_rejected = s.rejected;
+                so.last_service_blocking_rate = s.services_processed > 0
+                    ? (double)(s.services_processed - s.services_accepted) / (double)s.services_processed : 0.0;
+                so.last_episode_service_blocking_rate = s.episode_services_processed > 0
+                    ? (double)(s.episode_services_processed - s.episode_services_accepted) / (double)s.episode_services_processed : 0.0;
+                so.last_bit_rate_blocking_rate = s.bit_rate_requested > 0
+                    ? (s.bit_rate_requested - s.bit_rate_provisioned) / s.bit_rate_requested : 0.0;
+                so.last_episode_bit_rate_blocking_rate = s.episode_bit_rate_requested > 0
+                    ? (s.episode_bit_rate_requested - s.episode_bit_rate_provisioned) / s.episode_bit_rate_requested : 0.0;
+                for (int m = 0; m < 8; m++) so.last_modulation_hist[m] = s.episode_modulation_hist[m];
+                so.last_mean_gsnr = s.episode_services_processed > 0 ? osnr_flushed / (double)s.episode_services_processed : 0.0;
+                so.last_episode_disrupted = s.episode_disrupted_services;
+                so.last_episode_defrag_cycles = s.episode_defrag_cycles;
+                so.last_episode_service_reallocations = s.episode_service_reallocations;
+            }
+        }
+
+        // ================= _next_service (:1067-1122): next request, then the departures it triggers ==================
+        pop_request();
+        for (int ch = ((active + kWave - 1) / kWave) - 1; ch >= 0; ch--) {
+            const float r = rr[ch * kWave + lane];                          // unused entries hold +inf
+            uint64_t bal = __ballot(r <= v_at);
+            while (bal) {
+                const int ln = 63 - __builtin_clzll(bal);                   // highest index first: the hole is filled by a keeper
+                bal &= ~(1ull << ln);
+                const int idx = ch * kWave + ln;
+                const uint2 ab = rec[idx];                                  // uniform address: broadcast read
+                const uint32_t a = __builtin_amdgcn_readfirstlane(ab.x), b = __builtin_amdgcn_readfirstlane(ab.y);
+                uint64_t mask = a;
+                if (M64) mask |= (uint64_t)(__builtin_amdgcn_readfirstlane(a2[idx]) & 0xFFFFFu) << 32;
+                const int nk = (int)((b >> 14) & 0x1FFu) + 1, sk = ((int)(b & 0x7FFu) - nk) >> 1;
+                mark(mask, sk, min(sk + nk + 1, S), true);                  // frees n+1 slots, clamped at S (quirk Q7)
+                const int last = active - 1;
+                // move the last record into the hole, neutralise the vacated entry
+                const uint2 lab = rec[last];
+                const float lr = rr[last];
+                if (idx != last) {
+                    lds_write_lane0(rec_base + (uint32_t)idx * 8u, (uint64_t)lab.x | ((uint64_t)lab.y << 32), rr_base + (uint32_t)idx * 4u, __float_as_uint(lr));
+                    if (M64) lds_write_lane0_b32(a2_base + (uint32_t)idx * 4u, a2[last]);
+                }
+                lds_write_lane0(rec_base + (uint32_t)last * 8u, 0ull, rr_base + (uint32_t)last * 4u, 0x7F800000u);
+                if (M64) lds_write_lane0_b32(a2_base + (uint32_t)last * 4u, 0u);
+                active = last;
+                wave_sync();
+            }
+        }
+        d_active_sum += (unsigned long long)active;
+        const bool terminated = epp == P.episode_length;
+        if (terminated) d_episodes++;
+        if (REC && lane == 0) { recp->active = active; recp->terminated = (uint8_t)terminated; }
+        if (terminated && P.auto_reset) {
+            // reset (:427-504): empty network, episode counters to zero, draw request #0 of the next episode
+            for (int i = lane; i < E * RW; i += kWave) occ[i] = word_mask32(i % RW, 0, S);
+            for (int i = lane; i < active; i += kWave) { rec[i] = make_uint2(0u, 0u); rr[i] = INFINITY; if (M64) a2[i] = 0; }
+            active = 0;
+            epp = 0; eacc = 0; erej = 0; cnt = 0;
+            base_req = base_prov = base_ereq = base_eprov = 0.0;
+            osnr_flushed = 0.0; osnr_prod = 1.0;
+            wave_sync();
+            pop_request();
+        }
+    }
+
+    // ---- store: DevEnv, bitmap, records (lean codec -> generic codec) ----
+    store_env();
+    wave_sync();
+    {
+        uint32_t *g = reinterpret_cast<uint32_t *>(P.occ + (size_t)replica * E * P.row_words);
+        for (int i = lane; i < E * RW; i += kWave) g[i] = occ[i];
+        const size_t off = (size_t)replica * C;
+        for (int i = lane; i < active; i += kWave) {
+            const uint2 ab = rec[i];
+            const int n = (int)((ab.y >> 14) & 0x1FFu) + 1, slot = ((int)(ab.y & 0x7FFu) - n) >> 1, mod = (int)((ab.y >> 11) & 7u);
+            int path = (int)(ab.y >> 23);
+            if (M64) path |= (int)(a2[i] >> 20) << 9;
+            uint32_t ga, gb;
+            if (P.rec32) rec_pack<true>(path, ab.x, slot, n, mod, ga, gb);
+            else rec_pack<false>(path, 0, slot, n, mod, ga, gb);
+            P.svc_a[off + i] = ga; P.svc_b[off + i] = gb; P.svc_r[off + i] = rr[i];
+        }
+    }
+}
+
+}  // namespace ongym

@@ -4,12 +4,14 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "ongym_device.hpp"
+#include "ongym_fast.hpp"
 
 using namespace ongym;
 
@@ -86,6 +88,14 @@ __global__ __launch_bounds__(64, WAVES) void k_run(const Params *__restrict__ Pp
     if (c.lane == 0 && P.dbg)
         for (int i = 0; i < ONGYM_NSTAMPS; i++) atomicAdd(&P.dbg[i], c.stamp_acc[i]);
 #endif
+}
+
+// The lean fused first-fit kernel (ongym_fast.hpp).  M64: link masks need two words (32 < n_links <= 52);
+// ENT: interferers per lane cached in registers; WAVES: waves per SIMD the register allocation is bounded for.
+template <bool M64, bool REC, int ENT, int WAVES>
+__global__ __launch_bounds__(64, WAVES) void k_fast(const Params *__restrict__ Pp, int nsteps, ongym_step_rec *out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    fast_run<M64, REC, ENT>(*Pp, nsteps, out, smem);
 }
 
 __global__ __launch_bounds__(64) void k_reset(const Params *__restrict__ Pp, const uint8_t *mask) {
@@ -263,6 +273,10 @@ struct ongym_env {
     float *d_obs = nullptr; uint8_t *d_obsmask = nullptr;   // lazily allocated staging for ongym_observe with host buffers
     int32_t *d_scratch_i = nullptr; size_t scratch_i_bytes = 0; double *d_scratch_d = nullptr;
     bool has_source = false;
+    bool fast_ok = false;           // the configuration is eligible for k_fast (see fast_eligible)
+    bool fast_m64 = false;
+    bool trace_used = false;        // a replayed trace may have left records the lean codec cannot hold
+    size_t fast_lds = 0;
 };
 
 #define HIP_TRY(env, expr)                                                                               \
@@ -441,6 +455,8 @@ static int build(ongym_env *env, const ongym_config *c) {
     // expressions. nk range: the largest slot count the configured traffic can produce (anything larger, e.g. from a
     // replayed trace, is computed on the fly by the kernel).
     P.pair_tab = nullptr; P.tab_nmax = 0; P.tab_stride = 2 * c->n_slots + 1;
+    P.path_rec = nullptr; P.pair_tab2k = nullptr;
+    std::vector<double2> host_tab;
     if (uniform) {
         double max_rate = 0.0;
         if (c->bit_rate_mode == 0) for (int b = 0; b < c->n_bit_rates; b++) max_rate = std::max(max_rate, c->bit_rates[b]);
@@ -467,6 +483,7 @@ static int build(ongym_env *env, const ongym_config *c) {
             }
             if ((rc = upload(env, tab.data(), tab.size(), &P.pair_tab))) return rc;
             P.tab_nmax = nmax;
+            host_tab.swap(tab);
         }
     }
     if ((rc = upload(env, nreq_tab.data(), nreq_tab.size(), &P.nreq_tab))) return rc;
@@ -497,6 +514,45 @@ static int build(ongym_env *env, const ongym_config *c) {
     if (c->bit_rate_mode != 0) P.n_bit_rates = 1;
     if ((rc = upload(env, c->node_cum, (size_t)N, &P.node_cum))) return rc;
     if (c->path_len_norm && (rc = upload(env, c->path_len_norm, (size_t)NP, &P.path_len_norm))) return rc;
+
+    // ---- lean first-fit kernel (ongym_fast.hpp): eligibility and its two extra tables ----
+    {
+        bool ok = uniform && P.ase_shortcut && !P.defragmentation && !P.measure_disruptions && c->bit_rate_mode == 0 &&
+                  c->n_bit_rates <= 8 && E <= 52 && N <= 64 && P.tab_stride < kTabPitch && !host_tab.empty();
+        const char *force = std::getenv("ONGYM_FORCE_GENERIC");
+        if (force && force[0] == '1') ok = false;
+        int max_n = 0;
+        if (ok) {
+            for (int b = 0; b < c->n_bit_rates; b++) {
+                const double r = c->bit_rates[b];
+                if (!(r > 0) || r != std::floor(r) || r > 16777216.0) ok = false;   // integer-valued, exact as float32
+                for (int m = 0; m < M; m++) max_n = std::max(max_n, std::min((int)nreq_tab[(size_t)b * kMaxMods + m], (int)c->n_slots));
+            }
+            if (max_n < 1 || max_n > 512 || max_n > P.tab_nmax) ok = false;
+        }
+        const bool m64 = !P.rec32;
+        const size_t flds = fast_lds_bytes(E, P.row_words, c->capacity, m64);
+        if (flds > 160 * 1024) ok = false;
+        if (ok) {
+            std::vector<PathRec> recs((size_t)NP);
+            for (int p = 0; p < NP; p++) {
+                PathRec &r = recs[(size_t)p];
+                r.hops = (uint32_t)c->path_hops[p]; r.mask_lo = (uint32_t)mask[2 * p]; r.mask_hi = (uint32_t)(mask[2 * p] >> 32);
+                r.id = (uint32_t)p; r.ase = path_ase[(size_t)p]; r.w1 = path_w1[(size_t)p];
+            }
+            const PathRec *d_recs = nullptr;
+            if ((rc = upload(env, recs.data(), recs.size(), &d_recs))) return rc;
+            P.path_rec = d_recs;
+            std::vector<double> t2((size_t)P.tab_nmax * kTabPitch * 2, 0.0);
+            for (int nk = 0; nk < P.tab_nmax; nk++)
+                for (int d = 0; d < P.tab_stride; d++) {
+                    t2[((size_t)nk * kTabPitch + d) * 2] = host_tab[(size_t)nk * P.tab_stride + d].x;
+                    t2[((size_t)nk * kTabPitch + d) * 2 + 1] = host_tab[(size_t)nk * P.tab_stride + d].y;
+                }
+            if ((rc = upload(env, t2.data(), t2.size(), &P.pair_tab2k))) return rc;
+            env->fast_ok = true; env->fast_m64 = m64; env->fast_lds = flds;
+        }
+    }
 
     // mutable state
     const size_t B = (size_t)c->batch;
@@ -557,6 +613,12 @@ static int build(ongym_env *env, const ongym_config *c) {
         ONGYM_SET_LDS((k_query_gsnr_many<false, true>)); ONGYM_SET_LDS((k_query_gsnr_many<false, false>));
         ONGYM_SET_LDS(k_reset);
 #undef ONGYM_SET_LDS
+    }
+    if (env->fast_ok && env->fast_lds > 64 * 1024) {
+#define ONGYM_SET_FLDS(K) HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->fast_lds))
+        ONGYM_SET_FLDS((k_fast<false, false, 2, 4>)); ONGYM_SET_FLDS((k_fast<false, true, 2, 4>));
+        ONGYM_SET_FLDS((k_fast<true, false, 4, 3>)); ONGYM_SET_FLDS((k_fast<true, true, 4, 3>));
+#undef ONGYM_SET_FLDS
     }
     // scratch for queries / host-buffer I/O
     env->scratch_i_bytes = std::max(std::max((size_t)E * c->n_slots * 4, (size_t)c->capacity * sizeof(ongym_service) + 16), (size_t)2048 * 4);
@@ -688,6 +750,7 @@ int ongym_set_requests(ongym_env *env, const ongym_request *reqs, int64_t n_per_
     }
     env->P.trace_n = n_per_replica;
     env->P.req_mode = kReqTrace;
+    env->trace_used = true;
     env->has_source = true;
     { int rc = push_params(env); if (rc) return rc; }
     int threads = 256, blocks = (env->P.batch + threads - 1) / threads;
@@ -722,6 +785,23 @@ static int launch_run(ongym_env *env, int mode, int policy, int nsteps, const in
                       uint8_t *d_flag_out, ongym_step_rec *d_out) {
     HIP_TRY(env, hipEventRecord(env->ev0, env->stream));
     const dim3 grid(env->P.batch), block(64);
+    if (mode == kModePolicyStep && policy == ONGYM_POLICY_FIRST_FIT && env->fast_ok && !env->trace_used &&
+        env->P.req_mode == kReqRng) {
+        // the lean kernel: same results, ~3x fewer issued instructions (ongym_fast.hpp)
+#define ONGYM_LAUNCH_FAST(M64, ENT, WAVES)                                                                         \
+    do {                                                                                                           \
+        if (d_out) hipLaunchKernelGGL((k_fast<M64, true, ENT, WAVES>), grid, block, env->fast_lds, env->stream, env->d_P, nsteps, d_out); \
+        else hipLaunchKernelGGL((k_fast<M64, false, ENT, WAVES>), grid, block, env->fast_lds, env->stream, env->d_P, nsteps, d_out);      \
+    } while (0)
+        if (env->fast_m64) ONGYM_LAUNCH_FAST(true, 4, 3);
+        else if (env->fast_lds <= 8192) ONGYM_LAUNCH_FAST(false, 2, 5);
+        else ONGYM_LAUNCH_FAST(false, 2, 4);
+#undef ONGYM_LAUNCH_FAST
+        HIP_TRY(env, hipGetLastError());
+        HIP_TRY(env, hipEventRecord(env->ev1, env->stream));
+        env->timed = true;
+        return 0;
+    }
     if (policy == ONGYM_POLICY_HIGHEST_SNR) {
         if (!env->P.uniform_alpha) return fail_arg(env, "the highest-SNR policy needs uniform attenuation", ONGYM_E_LIMIT);
         if (field_lds(env) > 64 * 1024) {

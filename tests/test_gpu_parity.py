@@ -167,7 +167,9 @@ def test_random_traffic_vs_oracle(topo, S, load, steps):
                   "current_time", "active", "last_episode_accepted", "last_service_blocking_rate"):
             assert st[r][f] == o[f], (r, f, st[r][f], o[f])
         # the device may settle an evaluation by the ASE-only bound instead of the full interferer sum
-        assert st[r]["total_gn_evals"] + st[r]["total_gn_shortcuts"] == o["total_gn_evals"]
+        # (k_run: per candidate, so the sum is exact; the lean k_fast: per modulation before the bitmap is read, so
+        # it also counts modulations that had no candidate)
+        assert st[r]["total_gn_evals"] <= o["total_gn_evals"] <= st[r]["total_gn_evals"] + st[r]["total_gn_shortcuts"]
         assert st[r]["total_interferer_terms"] <= o["total_interferer_terms"]
         np.testing.assert_array_equal(st[r]["episode_modulation_hist"], o["episode_modulation_hist"])
         np.testing.assert_array_equal(env.grid(r), oracles[r].grid())
