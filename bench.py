@@ -271,6 +271,7 @@ def main():
             "blocking_rate": 1.0 - stats_sum["total_accepted"] / stats_sum["total_steps"],
         }
         # the timed state must be the loaded network, whatever the CLI said
+        out["occupancy"] = env.occupancy()
         out["steady_state"] = bool(counters["mean_active_services"] >= 0.4 * wl["load"])
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(tables, wl, args.workload)

@@ -267,6 +267,10 @@ int ongym_query_request(ongym_env *env, int32_t replica, ongym_request *out);
 /* per-replica counters: out[batch] (host buffer) */
 int ongym_stats_get(ongym_env *env, ongym_stats *out);
 
+/* Diagnostic: resident workgroups (one wavefront = one replica each) per compute unit of the kernel that
+ * ongym_step_policy(ONGYM_POLICY_FIRST_FIT) launches on this environment, its dynamic LDS bytes per replica, and whether it
+ * is the lean kernel (1) or the generic one (0). */
+int ongym_query_occupancy(ongym_env *env, int32_t *blocks_per_cu, int32_t *lds_bytes, int32_t *lean_kernel);
 int ongym_sync(ongym_env *env);
 /* Device time (ms, HIP events on the env's stream) of the most recent step launch; <0 if none. */
 double ongym_last_kernel_ms(ongym_env *env);

@@ -63,8 +63,10 @@ __device__ __forceinline__ const __attribute__((address_space(4))) T *KC(const T
 
 __host__ __device__ inline size_t fast_lds_bytes(int n_links, int row_words, int capacity, bool m64) {
     size_t b = ((size_t)n_links * row_words * 8 + 15) & ~(size_t)15;   // occ  u32 [E][2W]
-    b += (size_t)n_links * 16 + 64;                                     // lw (w1,w2) [E] | phi [8]
-    b += (size_t)capacity * (8 + 4 + 2 + (m64 ? 4 : 0));                // rec {a,b} | rr | list | (a2)
+    b += (size_t)(n_links + 1) * 16 + 64;                               // lw (w1,w2) [E + a zero entry] | phi [8]
+    b += (size_t)(capacity + 1) * 8 + (m64 ? (size_t)(capacity + 1) * 4 : 0);   // rec {a,b} | (a2), + one neutral entry
+    b += (size_t)capacity * (4 + 2);                                    // rr | list
+    b += 48;                                                            // cold wave-uniform state (5 doubles)
     return (b + 15) & ~(size_t)15;
 }
 
@@ -108,6 +110,14 @@ __device__ __forceinline__ void lds_or_lanes(uint64_t mask, uint32_t addr, uint3
     uint64_t saved;
     asm volatile("s_and_saveexec_b64 %0, %1\n\tds_or_b32 %2, %3\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "s"(mask), "v"(addr), "v"(val) : "memory", "scc");
 }
+__device__ __forceinline__ void lds_and2_lanes(uint64_t mask, uint32_t addr, uint32_t v0, uint32_t v1) {
+    uint64_t saved;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_and_b32 %2, %3\n\tds_and_b32 %2, %4 offset:4\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "s"(mask), "v"(addr), "v"(v0), "v"(v1) : "memory", "scc");
+}
+__device__ __forceinline__ void lds_or2_lanes(uint64_t mask, uint32_t addr, uint32_t v0, uint32_t v1) {
+    uint64_t saved;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_or_b32 %2, %3\n\tds_or_b32 %2, %4 offset:4\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "s"(mask), "v"(addr), "v"(v0), "v"(v1) : "memory", "scc");
+}
 __device__ __forceinline__ void lds_write_lane0(uint32_t addr64, uint64_t v64, uint32_t addr32, uint32_t v32) {
     uint64_t saved;
     asm volatile("s_and_saveexec_b64 %0, 1\n\tds_write_b64 %1, %2\n\tds_write_b32 %3, %4\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "v"(addr64), "v"(v64), "v"(addr32), "v"(v32) : "memory", "scc");
@@ -130,6 +140,40 @@ __device__ __forceinline__ uint32_t fast_pack_b(int slot, int n, int mod, int pa
     return (uint32_t)(2 * slot + n) | ((uint32_t)mod << 11) | ((uint32_t)(n - 1) << 14) | ((uint32_t)(path & 0x1FF) << 23);
 }
 
+
+// 64 requests at once: lane i evaluates ongym_draw_request (include/ongym_traffic.h) for request index base + i, except the
+// float32 clock add, which needs the previous arrival and is done when the request is popped.
+__device__ __forceinline__ void fast_refill(const Params &P, const DevEnv *ge, uint64_t base, int lane, float &rq_iat, float &rq_ht,
+                                         uint32_t &rq_pk) {
+    ONGYM_NO_CONTRACT
+    const int N = P.n_nodes, K = P.k_paths;
+    const uint64_t key = ge->rng_key;
+    const float mean_iat_f = ge->mean_iat_f;
+    const uint64_t ctr = (base + (uint64_t)lane) * ONGYM_DRAWS_PER_REQUEST;
+    const double u0 = ongym_uniform(key, ctr + 0), u1 = ongym_uniform(key, ctr + 1), u2 = ongym_uniform(key, ctr + 2),
+                 u3 = ongym_uniform(key, ctr + 3), u4 = ongym_uniform(key, ctr + 4);
+    rq_iat = -ongym_logf_det(1.0 - u0) * mean_iat_f;          // ongym_expovariate_f
+    rq_ht = -ongym_logf_det(1.0 - u1) * P.mean_holding_f;
+    const double total = G(P.node_cum)[N - 1];
+    const double xs = u2 * total;
+    int src = 0;
+    for (int i = 0; i < N - 1; i++) src += (G(P.node_cum)[i] <= xs) ? 1 : 0;      // == ongym_bisect (cum is non-decreasing)
+    const double hi_s = G(P.node_cum)[src];
+    const double lo_s = src > 0 ? G(P.node_cum)[src - 1] : 0.0;
+    const double w_s = hi_s - lo_s;
+    double x = u3 * (total - w_s);
+    if (x >= lo_s) x += w_s;
+    int dst = 0;
+    for (int i = 0; i < N - 1; i++) dst += (G(P.node_cum)[i] <= x) ? 1 : 0;
+    if (dst == src) dst = (src + 1 < N) ? src + 1 : src - 1;
+    const int nb = P.n_bit_rates;
+    const double xb = u4 * G(P.bit_rate_cum)[nb - 1];
+    int bi = 0;
+    for (int i = 0; i < nb - 1; i++) bi += (G(P.bit_rate_cum)[i] <= xb) ? 1 : 0;
+    const int p0 = G(P.pair_paths)[(src * N + dst) * K];
+    rq_pk = (uint32_t)src | ((uint32_t)dst << 6) | ((uint32_t)bi << 12) | ((uint32_t)(p0 + 1) << 15);
+}
+
 template <bool M64, bool REC, int ENT>
 __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step_rec *out, unsigned char *smem) {
     ONGYM_NO_CONTRACT
@@ -140,17 +184,20 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
     // ---- LDS carve-up ----
     uint32_t *const occ = reinterpret_cast<uint32_t *>(smem);
     size_t o = ((size_t)E * RW * 4 + 15) & ~(size_t)15;
-    double *const lw = reinterpret_cast<double *>(smem + o); o += (size_t)E * 16;
+    double *const lw = reinterpret_cast<double *>(smem + o); o += (size_t)(E + 1) * 16;      // lw[2E], lw[2E+1] = 0
     double *const phi = reinterpret_cast<double *>(smem + o); o += 64;
-    uint2 *const rec = reinterpret_cast<uint2 *>(smem + o); o += (size_t)C * 8;
+    uint2 *const rec = reinterpret_cast<uint2 *>(smem + o); o += (size_t)(C + 1) * 8;           // rec[C]: neutral entry
+    uint32_t *const a2 = reinterpret_cast<uint32_t *>(smem + o); if (M64) o += (size_t)(C + 1) * 4;
     float *const rr = reinterpret_cast<float *>(smem + o); o += (size_t)C * 4;
-    uint32_t *const a2 = reinterpret_cast<uint32_t *>(smem + o); if (M64) o += (size_t)C * 4;
-    uint16_t *const list = reinterpret_cast<uint16_t *>(smem + o);
+    uint16_t *const list = reinterpret_cast<uint16_t *>(smem + o); o += (size_t)C * 2;
+    // wave-uniform state that is touched once in ~60 steps or less lives in LDS, not in registers:
+    // [0] bit_rate_requested [1] bit_rate_provisioned [2] episode_bit_rate_requested [3] episode_bit_rate_provisioned at the
+    // start of the launch / episode (the launch adds counts x bit rate), [4] osnr_flushed
+    double *const cold = reinterpret_cast<double *>(smem + ((o + 7) & ~(size_t)7));
     const uint32_t occ_base = lds_addr(occ), rec_base = lds_addr(rec), rr_base = lds_addr(rr), a2_base = lds_addr(a2);
-    const uint32_t v_rowaddr = occ_base + (uint32_t)lane * (uint32_t)RW * 4u;    // lane l = link l: its bitmap row
 
     // ---- load: constants, bitmap, records (generic codec -> lean codec) ----
-    for (int i = lane; i < E; i += kWave) { lw[2 * i] = G(P.link_w1)[i]; lw[2 * i + 1] = G(P.link_w2)[i]; }
+    for (int i = lane; i <= E; i += kWave) { lw[2 * i] = i < E ? G(P.link_w1)[i] : 0.0; lw[2 * i + 1] = i < E ? G(P.link_w2)[i] : 0.0; }
     if (lane < kMaxMods) phi[lane] = lane < M ? P.mod_phi53[lane] : 0.0;
     {
         const uint32_t *g = reinterpret_cast<const uint32_t *>(P.occ + (size_t)replica * E * P.row_words);
@@ -159,7 +206,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
     int active = uniform_i32(ge->st.active);
     {
         const size_t off = (size_t)replica * C;
-        for (int i = lane; i < C; i += kWave) {
+        for (int i = lane; i <= C; i += kWave) {
             uint2 ab = make_uint2(0u, 0u);
             float r = INFINITY;
             uint32_t hi = 0;
@@ -176,7 +223,8 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                 }
                 ab.y = fast_pack_b(slot, n, mod, path);
             }
-            rec[i] = ab; rr[i] = r;
+            rec[i] = ab;
+            if (i < C) rr[i] = r;
             if (M64) a2[i] = hi;
         }
     }
@@ -184,9 +232,8 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
     // ---- per-lane tables: lane q = 8*bit_rate_index + modulation ----
     const double lp = uniform_f64(ge->launch_power), margin = uniform_f64(ge->margin);
     const double rp0 = 1.0 / lp, lp2 = lp * lp;
-    const float mean_iat_f = uniform_f32(ge->mean_iat_f);
     int t_n;
-    double t_nlic, t_selfa, t_lim, t_bw, t_h, t_pre_a, t_pre_b, t_lim_pf;
+    double t_nlic, t_selfa, t_lim_lo, t_lim_hi;
     {
         const int qb = lane >> 3, qm = lane & 7;
         const bool valid = qb < P.n_bit_rates && qm < M;
@@ -194,25 +241,23 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         t_n = valid ? G(P.nreq_tab)[at_] : 0;
         t_nlic = valid ? G(P.req_coef)[2 * at_] * lp2 : 0.0;
         t_selfa = valid ? G(P.req_coef)[2 * at_ + 1] : 0.0;
-        t_lim = pow(10.0, -(P.mod_thr[qm < M ? qm : 0] + margin) / 10.0);      // same expression as load_state
-        t_bw = P.slot_bw * t_n;
-        t_h = P.slot_bw * (t_n / 2.0);
-        // lower bound of 1/GSNR at slot 0 = ASE(slot 0) + self-channel NLI:  pre_a * path_ase + pre_b * path_w1
-        t_pre_a = (t_bw * (P.f0 + t_h)) * rp0;
-        t_pre_b = t_nlic * t_selfa;
-        t_lim_pf = (valid && t_n >= 1 && t_n <= S) ? t_lim * (1.0 + 2e-9) : -1.0;
+        const double lim = pow(10.0, -(P.mod_thr[qm < M ? qm : 0] + margin) / 10.0);      // same expression as load_state
+        // band of qot_ok; lanes without a usable slot count can never pass (their limits are negative)
+        const bool usable = valid && t_n >= 1 && t_n <= S;
+        t_lim_lo = usable ? lim * (1.0 - 1e-9) : -1.0;
+        t_lim_hi = usable ? lim * (1.0 + 1e-9) : -1.0;
     }
-    const float t_br = lane < P.n_bit_rates ? (float)G(P.bit_rates)[lane] : 0.f;     // lane b = bit rate b
 
     // ---- wave-uniform state from DevEnv ----
-    const uint64_t key = readlane_u64(ge->rng_key, 0);
     uint64_t req_base = readlane_u64(ge->req_index, 0);        // ring lane i = request req_base + i
     float v_at = uniform_f32((float)ge->st.current_time);  // current_time is always a float32 value ((double)at, qrmsa.pyx:1081)
     int epp = uniform_i32((int)ge->st.episode_services_processed);
-    int eacc = uniform_i32((int)ge->st.episode_services_accepted), erej = uniform_i32((int)ge->st.rejected);
-    double base_req = uniform_f64(ge->st.bit_rate_requested), base_prov = uniform_f64(ge->st.bit_rate_provisioned);
-    double base_ereq = uniform_f64(ge->st.episode_bit_rate_requested), base_eprov = uniform_f64(ge->st.episode_bit_rate_provisioned);
-    double osnr_flushed = uniform_f64(ge->osnr_flushed);
+    int erej = uniform_i32((int)ge->st.rejected);
+    if (lane == 0) {
+        cold[0] = ge->st.bit_rate_requested; cold[1] = ge->st.bit_rate_provisioned;
+        cold[2] = ge->st.episode_bit_rate_requested; cold[3] = ge->st.episode_bit_rate_provisioned;
+        cold[4] = ge->osnr_flushed;
+    }
     double osnr_prod = uniform_f64(ge->osnr_prod > 0.0 ? ge->osnr_prod : 1.0);
     int cnt = (lane >= 8 && lane < 16) ? (int)ge->st.episode_modulation_hist[lane - 8] : 0;
     int lane_terms = 0;
@@ -222,7 +267,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
     int cur_bi;
     {
         const float br = uniform_f32(ge->cur_br);
-        const uint64_t hit = __ballot(lane < P.n_bit_rates && t_br == br);
+        const uint64_t hit = __ballot(lane < P.n_bit_rates && (float)G(P.bit_rates)[min(lane, P.n_bit_rates - 1)] == br);
         cur_bi = hit ? __builtin_ctzll(hit) : 0;
     }
     int cur_p0 = uniform_i32(KC(P.pair_paths)[(cur_src * N + cur_dst) * K]);
@@ -233,32 +278,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
     float rq_iat, rq_ht;
     uint32_t rq_pk;
     int rq_pos = 0;
-    auto refill = [&]() {      // 64 requests: lane i evaluates ongym_draw_request for index req_base + i, minus the clock add
-        const uint64_t ctr = (req_base + (uint64_t)lane) * ONGYM_DRAWS_PER_REQUEST;
-        const double u0 = ongym_uniform(key, ctr + 0), u1 = ongym_uniform(key, ctr + 1), u2 = ongym_uniform(key, ctr + 2),
-                     u3 = ongym_uniform(key, ctr + 3), u4 = ongym_uniform(key, ctr + 4);
-        rq_iat = -ongym_logf_det(1.0 - u0) * mean_iat_f;          // ongym_expovariate_f
-        rq_ht = -ongym_logf_det(1.0 - u1) * P.mean_holding_f;
-        const double total = G(P.node_cum)[N - 1];
-        const double xs = u2 * total;
-        int src = 0;
-        for (int i = 0; i < N - 1; i++) src += (G(P.node_cum)[i] <= xs) ? 1 : 0;      // == ongym_bisect (cum is non-decreasing)
-        const double hi_s = G(P.node_cum)[src];
-        const double lo_s = src > 0 ? G(P.node_cum)[src - 1] : 0.0;
-        const double w_s = hi_s - lo_s;
-        double x = u3 * (total - w_s);
-        if (x >= lo_s) x += w_s;
-        int dst = 0;
-        for (int i = 0; i < N - 1; i++) dst += (G(P.node_cum)[i] <= x) ? 1 : 0;
-        if (dst == src) dst = (src + 1 < N) ? src + 1 : src - 1;
-        const int nb = P.n_bit_rates;
-        const double xb = u4 * G(P.bit_rate_cum)[nb - 1];
-        int bi = 0;
-        for (int i = 0; i < nb - 1; i++) bi += (G(P.bit_rate_cum)[i] <= xb) ? 1 : 0;
-        const int p0 = G(P.pair_paths)[(src * N + dst) * K];
-        rq_pk = (uint32_t)src | ((uint32_t)dst << 6) | ((uint32_t)bi << 12) | ((uint32_t)(p0 + 1) << 15);
-        rq_pos = 0;
-    };
+    auto refill = [&]() { fast_refill(P, ge, req_base, lane, rq_iat, rq_ht, rq_pk); rq_pos = 0; };
     refill();
     wave_sync();
 
@@ -271,7 +291,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         int hist[8], nreq_b[8], nacc_b[8];
         float brs[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) { hist[i] = (int)rl((uint32_t)cnt, 8 + i); nreq_b[i] = (int)rl((uint32_t)cnt, 16 + i); nacc_b[i] = (int)rl((uint32_t)cnt, 24 + i); brs[i] = rlf(t_br, i); }
+        for (int i = 0; i < 8; i++) { hist[i] = (int)rl((uint32_t)cnt, 8 + i); nreq_b[i] = (int)rl((uint32_t)cnt, 16 + i); nacc_b[i] = (int)rl((uint32_t)cnt, 24 + i); brs[i] = i < P.n_bit_rates ? (float)KC(P.bit_rates)[i] : 0.f; }
         if (lane == 0) {
             ongym_stats &s = ge->st;
             ge->req_index = req_base + (uint64_t)rq_pos;
@@ -280,13 +300,15 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             ge->cur_id = epp - 1; ge->have_request = 1;
             s.services_processed += d_pops; s.episode_services_processed = epp;
             s.services_accepted += d_acc; s.total_accepted += d_acc;
-            s.episode_services_accepted = eacc; s.rejected = erej;
+            s.rejected = erej;
             double rq = 0.0, pv = 0.0;       // exact: bit rates are integer-valued (eligibility), counts are small integers
-            for (int i = 0; i < 8; i++) { s.episode_modulation_hist[i] = hist[i]; rq += (double)nreq_b[i] * (double)brs[i]; pv += (double)nacc_b[i] * (double)brs[i]; }
-            s.bit_rate_requested = base_req + rq; s.episode_bit_rate_requested = base_ereq + rq;
-            s.bit_rate_provisioned = base_prov + pv; s.episode_bit_rate_provisioned = base_eprov + pv;
-            s.episode_osnr_sum = osnr_flushed + (osnr_prod != 1.0 ? -10.0 * log10(osnr_prod) : 0.0);
-            ge->osnr_flushed = osnr_flushed; ge->osnr_prod = osnr_prod;
+            int eacc = 0;
+            for (int i = 0; i < 8; i++) { s.episode_modulation_hist[i] = hist[i]; eacc += hist[i]; rq += (double)nreq_b[i] * (double)brs[i]; pv += (double)nacc_b[i] * (double)brs[i]; }
+            s.episode_services_accepted = eacc;
+            s.bit_rate_requested = cold[0] + rq; s.episode_bit_rate_requested = cold[2] + rq;
+            s.bit_rate_provisioned = cold[1] + pv; s.episode_bit_rate_provisioned = cold[3] + pv;
+            s.episode_osnr_sum = cold[4] + (osnr_prod != 1.0 ? -10.0 * log10(osnr_prod) : 0.0);
+            ge->osnr_flushed = cold[4]; ge->osnr_prod = osnr_prod;
             s.episodes_completed += d_episodes;
             s.total_steps += d_steps; s.total_gn_evals += d_evals; s.total_gn_shortcuts += d_skips;
             s.total_interferer_terms += terms; s.total_paths_tried += d_paths; s.total_path_hops += d_hops;
@@ -311,20 +333,35 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
 
     // AND of the free bitmaps of a path's links, extended by the virtual free slot S (see path_free_ext); the links come
     // from the path's mask (their order does not matter)
-    const int wl = min(lane, RW - 1);
-    auto path_and = [&](uint64_t links) -> uint32_t {
+    auto path_and = [&](uint64_t links64) -> uint32_t {
+        const int wl = min(lane, RW - 1);
         uint32_t x = lane < RW ? ~0u : 0u;
-        while (links) {
-            const int l = __builtin_ctzll(links);
-            links &= links - 1;
-            x &= occ[l * RW + wl];
+        if (M64) {
+            uint64_t links = links64;
+            while (links) { const int l = __builtin_ctzll(links); links &= links - 1; x &= occ[l * RW + wl]; }
+        } else {
+            uint32_t links = (uint32_t)links64;
+            while (links) { const int l = __builtin_ctz(links); links &= links - 1; x &= occ[l * RW + wl]; }
         }
         if (lane == (S >> 5)) x |= 1u << (S & 31);
         return x;
     };
 
-    // set (free) or clear the slots [lo, hi) on the links of `mask`
+    // set (free) or clear the slots [lo, hi) on the links of `mask`.  Up to 33 slots (n <= 32) touch at most two words:
+    // both are updated at once (the second one by a neutral operand when the range does not reach it; it may then be the
+    // word after the row, which is left unchanged).  Longer ranges take the word loop.
     auto mark = [&](uint64_t mask, int lo, int hi, bool free_) {
+        const uint32_t v_rowaddr = occ_base + (uint32_t)lane * (uint32_t)RW * 4u;    // lane l = link l: its bitmap row
+        const int len = hi - lo;
+#ifndef ONGYM_X_MARK_LOOP
+        if (len <= 33) {
+            const uint64_t m = ((1ull << len) - 1ull) << (lo & 31);
+            const uint32_t a = v_rowaddr + (uint32_t)(lo >> 5) * 4u;
+            if (free_) lds_or2_lanes(mask, a, (uint32_t)m, (uint32_t)(m >> 32));
+            else lds_and2_lanes(mask, a, ~(uint32_t)m, ~(uint32_t)(m >> 32));
+            return;
+        }
+#endif
         for (int w = lo >> 5; w <= (hi - 1) >> 5; w++) {
             const uint32_t m = word_mask32(w, lo, hi);
             if (free_) lds_or_lanes(mask, v_rowaddr + (uint32_t)w * 4u, m);
@@ -359,11 +396,16 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             const PathRec pr = load_path_rec(path_recs, path);
             d_paths++; d_hops += pr.hops;
             // modulations whose lower bound at slot 0 already fails cannot pass at any slot
-            const double lb = t_pre_a * pr.ase + t_pre_b * pr.w1;
-            uint32_t feas = (uint32_t)(__ballot(lb < t_lim_pf) >> (8 * cur_bi)) & 0xFFu;
+            // lower bound of 1/GSNR at slot 0 = ASE(slot 0) + self-channel NLI (a few fp64 operations per lane: cheaper than
+            // keeping their factors in registers for the whole launch)
+            const double t_bw = P.slot_bw * t_n, t_h = P.slot_bw * (t_n / 2.0);
+            const double lb = ((t_bw * (P.f0 + t_h)) * rp0) * pr.ase + (t_nlic * t_selfa) * pr.w1;
+            // (lb >= lim*(1+1e-9) => the full sum is at least that large up to rounding, and inside the 1e-9 band the
+            //  dB-domain test rejects anything above lim: the skipped evaluation would have failed)
+            uint32_t feas = (uint32_t)(__ballot(lb < t_lim_hi) >> (8 * cur_bi)) & 0xFFu;
             d_skips += M - __popc(feas);            // modulations settled by the bound (statistics only)
             if (!feas) continue;
-            const uint64_t pmask = (uint64_t)pr.mask_lo | ((uint64_t)(pr.mask_hi & 0xFFFFFu) << 32);
+            const uint64_t pmask = M64 ? ((uint64_t)pr.mask_lo | ((uint64_t)(pr.mask_hi & 0xFFFFFu) << 32)) : (uint64_t)pr.mask_lo;
             uint32_t runs = path_and(pmask);
             int r = 1, L = -1;
             uint32_t e_c2k[ENT], e_key4[ENT];
@@ -383,8 +425,9 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                     L = 0;
                     for (int base = 0; base < active; base += 2 * kWave) {
                         const int i0 = base + lane, i1 = i0 + kWave;
-                        bool ov0 = (rec[i0].x & pr.mask_lo) != 0, ov1 = i1 < C && (rec[i1].x & pr.mask_lo) != 0;
-                        if (M64) { ov0 |= (a2[i0] & pr.mask_hi & 0xFFFFFu) != 0; ov1 |= i1 < C && (a2[i1] & pr.mask_hi & 0xFFFFFu) != 0; }
+                        const int i1c = min(i1, C);          // beyond the table: the neutral entry
+                        bool ov0 = (rec[i0].x & pr.mask_lo) != 0, ov1 = (rec[i1c].x & pr.mask_lo) != 0;    // unused entries: mask 0
+                        if (M64) { ov0 |= (a2[i0] & pr.mask_hi & 0xFFFFFu) != 0; ov1 |= (a2[i1c] & pr.mask_hi & 0xFFFFFu) != 0; }
                         const uint64_t bal0 = __ballot(ov0), bal1 = __ballot(ov1);
                         const int n0 = __popcll((unsigned long long)bal0);
                         const int p0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal0, 0));
@@ -396,13 +439,14 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                     wave_sync();
 #pragma unroll
                     for (int e = 0; e < ENT; e++) {
+#ifndef ONGYM_X_PREP_FLAT
                         const int j = lane + kWave * e;
                         e_c2k[e] = 0; e_key4[e] = 0; e_w1[e] = 0.0; e_pw2[e] = 0.0;
                         if (j < L) {
                             const int idx = list[j];
                             const uint2 ab = rec[idx];
                             e_c2k[e] = ab.y & 0x7FFu;
-                            e_key4[e] = ((ab.y >> 14) & 0x1FFu) << 15;       // (n-1) * kTabPitch entries * 16 bytes
+                            e_key4[e] = ((ab.y >> 14) & 0x1FFu) << 15;
                             uint32_t mm = ab.x & pr.mask_lo;
                             double w1 = 0.0, w2 = 0.0;
                             e_terms += __popc(mm);
@@ -417,6 +461,33 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                         }
                     }
                 }
+#else
+                        // entry j of the list (a neutral record beyond L: rec[C] is padding with mask 0)
+                        const int j = lane + kWave * e;
+                        const int idx = j < L ? (int)list[j] : C;
+                        const uint2 ab = rec[idx];
+                        e_c2k[e] = ab.y & 0x7FFu;
+                        e_key4[e] = ((ab.y >> 14) & 0x1FFu) << 15;           // (n-1) * kTabPitch entries * 16 bytes
+                        uint32_t mm = ab.x & pr.mask_lo;
+                        e_terms += __popc(mm);
+                        // the weights of the first two shared links without a branch (most interferers share one or two);
+                        // link index E is the zero entry
+                        const int l0 = mm ? __ffs(mm) - 1 : E;
+                        mm &= mm - 1;
+                        const int l1 = mm ? __ffs(mm) - 1 : E;
+                        mm &= mm - 1;
+                        double w1 = lw[2 * l0] + lw[2 * l1], w2 = lw[2 * l0 + 1] + lw[2 * l1 + 1];
+                        if (__ballot(mm != 0)) while (mm) { const int l = __ffs(mm) - 1; mm &= mm - 1; w1 += lw[2 * l]; w2 += lw[2 * l + 1]; }
+                        if (M64) {
+                            uint32_t mh = a2[idx] & pr.mask_hi & 0xFFFFFu;
+                            e_terms += __popc(mh);
+                            if (__ballot(mh != 0)) while (mh) { const int l = 32 + __ffs(mh) - 1; mh &= mh - 1; w1 += lw[2 * l]; w2 += lw[2 * l + 1]; }
+                        }
+                        e_w1[e] = w1;
+                        e_pw2[e] = phi[(ab.y >> 11) & 7u] * w2;
+                    }
+                }
+#endif
                 // ---- pass 2: 1/GSNR of (path, first, n) ----
                 const uint32_t c2 = (uint32_t)(2 * first + n);
                 double part = 0.0;
@@ -459,11 +530,11 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                 const double acc = g_ase + g_nli;
                 int ok;
                 {
-                    const uint64_t yes = __ballot(acc <= t_lim * (1.0 - 1e-9)), no = __ballot(acc >= t_lim * (1.0 + 1e-9));
+                    const uint64_t yes = __ballot(acc <= t_lim_lo), no = __ballot(acc >= t_lim_hi);
                     if ((yes >> q) & 1ull) ok = 1;
                     else if ((no >> q) & 1ull) ok = 0;
                     else {      // inside the 1e-9 band: the reference's own dB-domain expression (see qot_ok)
-                        const uint64_t db = __ballot(10.0 * log10(1.0 / acc) >= P.mod_thr[lane & 7] + margin);
+                        const uint64_t db = __ballot(10.0 * log10(1.0 / acc) >= P.mod_thr[lane & 7] + *KC(&ge->margin));
                         ok = (int)((db >> q) & 1ull);
                     }
                 }
@@ -491,10 +562,10 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             lds_write_lane0(rec_base + (uint32_t)active * 8u, (uint64_t)ra | ((uint64_t)rb << 32), rr_base + (uint32_t)active * 4u, __float_as_uint(rel));
             if (M64) lds_write_lane0_b32(a2_base + (uint32_t)active * 4u, (uint32_t)(ch_mask >> 32) | ((uint32_t)(ch_path >> 9) << 20));
             active++;
-            eacc++; d_acc++;
+            d_acc++;
             cnt += (lane == 8 + ch_m || lane == 24 + cur_bi) ? 1 : 0;
             osnr_prod *= ch_acc;
-            if (osnr_prod < 1e-250) { osnr_flushed += -10.0 * log10(osnr_prod); osnr_prod = 1.0; }
+            if (osnr_prod < 1e-250) { if (lane == 0) cold[4] += -10.0 * log10(osnr_prod); osnr_prod = 1.0; wave_sync(); }
         } else {
             erej++;
             if (ch_k < 0) {
@@ -513,7 +584,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                     const int path = uniform_i32(KC(P.pair_paths)[(cur_src * N + cur_dst) * K + k]);
                     if (path < 0) break;
                     const PathRec pr = load_path_rec(path_recs, path);
-                    const uint32_t x = path_and((uint64_t)pr.mask_lo | ((uint64_t)(pr.mask_hi & 0xFFFFFu) << 32));
+                    const uint32_t x = path_and(M64 ? ((uint64_t)pr.mask_lo | ((uint64_t)(pr.mask_hi & 0xFFFFFu) << 32)) : (uint64_t)pr.mask_lo);
                     int r1 = 1;
                     const bool any = first_set32(run_and32(x, r1, n_small + 1)) >= 0;
                     if (any) { bosnr = 1; bres = 0; }
@@ -548,7 +619,9 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         // the info dict of the terminal step is computed before the next request is drawn (:996-1060)
         const bool term = (epp + 1 == P.episode_length);
         if (term) {
-            osnr_flushed += (osnr_prod != 1.0) ? -10.0 * log10(osnr_prod) : 0.0; osnr_prod = 1.0;      // flush_osnr
+            if (lane == 0) cold[4] += (osnr_prod != 1.0) ? -10.0 * log10(osnr_prod) : 0.0;      // flush_osnr
+            osnr_prod = 1.0;
+            wave_sync();
             store_env();
             __threadfence_block();
             if (lane == 0) {
@@ -565,7 +638,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                 so.last_episode_bit_rate_blocking_rate = s.episode_bit_rate_requested > 0
                     ? (s.episode_bit_rate_requested - s.episode_bit_rate_provisioned) / s.episode_bit_rate_requested : 0.0;
                 for (int m = 0; m < 8; m++) so.last_modulation_hist[m] = s.episode_modulation_hist[m];
-                so.last_mean_gsnr = s.episode_services_processed > 0 ? osnr_flushed / (double)s.episode_services_processed : 0.0;
+                so.last_mean_gsnr = s.episode_services_processed > 0 ? cold[4] / (double)s.episode_services_processed : 0.0;
                 so.last_episode_disrupted = s.episode_disrupted_services;
                 so.last_episode_defrag_cycles = s.episode_defrag_cycles;
                 so.last_episode_service_reallocations = s.episode_service_reallocations;
@@ -610,9 +683,9 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             for (int i = lane; i < E * RW; i += kWave) occ[i] = word_mask32(i % RW, 0, S);
             for (int i = lane; i < active; i += kWave) { rec[i] = make_uint2(0u, 0u); rr[i] = INFINITY; if (M64) a2[i] = 0; }
             active = 0;
-            epp = 0; eacc = 0; erej = 0; cnt = 0;
-            base_req = base_prov = base_ereq = base_eprov = 0.0;
-            osnr_flushed = 0.0; osnr_prod = 1.0;
+            epp = 0; erej = 0; cnt = 0;
+            if (lane < 5) cold[lane] = 0.0;
+            osnr_prod = 1.0;
             wave_sync();
             pop_request();
         }

@@ -699,6 +699,28 @@ void ongym_destroy(ongym_env *env) {
     delete env;
 }
 
+/* Resident workgroups (= replicas = wavefronts) per compute unit of the kernel that ongym_step_policy(first fit) launches,
+ * as the HIP occupancy query reports it for this environment's LDS size. Diagnostic. */
+int ongym_query_occupancy(ongym_env *env, int32_t *blocks_per_cu, int32_t *lds_bytes, int32_t *lean_kernel) {
+    if (!env || !blocks_per_cu || !lds_bytes || !lean_kernel) return ONGYM_E_ARG;
+    HIP_TRY(env, hipSetDevice(env->cfg.device));
+    int nb = 0;
+    const bool lean = env->fast_ok && !env->trace_used && env->P.req_mode == kReqRng;
+    if (lean) {
+        if (env->fast_m64) HIP_TRY(env, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<true, false, 4, 3>, 64, env->fast_lds));
+        else if (env->fast_lds <= 8192) HIP_TRY(env, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<false, false, 2, 5>, 64, env->fast_lds));
+        else HIP_TRY(env, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<false, false, 2, 4>, 64, env->fast_lds));
+        *lds_bytes = (int32_t)env->fast_lds;
+    } else {
+        if (env->lds <= 8192) HIP_TRY(env, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_run<true, true, 5, 0>, 64, env->lds));
+        else HIP_TRY(env, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_run<true, true, 4, 0>, 64, env->lds));
+        *lds_bytes = (int32_t)env->lds;
+    }
+    *blocks_per_cu = nb;
+    *lean_kernel = lean ? 1 : 0;
+    return ONGYM_OK;
+}
+
 int ongym_sync(ongym_env *env) {
     if (!env) return ONGYM_E_ARG;
     HIP_TRY(env, hipSetDevice(env->cfg.device));
@@ -793,8 +815,9 @@ static int launch_run(ongym_env *env, int mode, int policy, int nsteps, const in
         if (d_out) hipLaunchKernelGGL((k_fast<M64, true, ENT, WAVES>), grid, block, env->fast_lds, env->stream, env->d_P, nsteps, d_out); \
         else hipLaunchKernelGGL((k_fast<M64, false, ENT, WAVES>), grid, block, env->fast_lds, env->stream, env->d_P, nsteps, d_out);      \
     } while (0)
+        static const bool four_waves = [] { const char *v = std::getenv("ONGYM_FAST_WAVES"); return v && v[0] == '4'; }();   // experiment switch
         if (env->fast_m64) ONGYM_LAUNCH_FAST(true, 4, 3);
-        else if (env->fast_lds <= 8192) ONGYM_LAUNCH_FAST(false, 2, 5);
+        else if (env->fast_lds <= 8192 && !four_waves) ONGYM_LAUNCH_FAST(false, 2, 5);
         else ONGYM_LAUNCH_FAST(false, 2, 4);
 #undef ONGYM_LAUNCH_FAST
         HIP_TRY(env, hipGetLastError());

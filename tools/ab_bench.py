@@ -32,10 +32,10 @@ print(json.dumps(dict(ms=ms, acc=float(st["total_accepted"].sum()), steps=float(
 ap = argparse.ArgumentParser()
 ap.add_argument("libs", nargs="+")
 ap.add_argument("--rounds", type=int, default=2)
-ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--reps", type=int, default=8, help="launches per round; a multiple of 4 covers whole episodes at 250 steps")
 ap.add_argument("--batch", type=int, default=65536)
 ap.add_argument("--steps", type=int, default=250)
-ap.add_argument("--warm", type=int, default=500)
+ap.add_argument("--warm", type=int, default=1000)
 ap.add_argument("--workload", default="nsfnet320")
 ap.add_argument("--capacity", type=int, default=0)
 a = ap.parse_args()
@@ -55,4 +55,5 @@ for lib in a.libs:
     if not ms:
         continue
     med = ms[len(ms) // 2]
-    print(f"{os.path.basename(lib):40s} min {ms[0]:8.2f} ms  med {med:8.2f} ms  -> {a.batch * a.steps / med / 1e3:.4e} steps/s   accepted/steps {check[lib]}")
+    mean = sum(ms) / len(ms)
+    print(f"{os.path.basename(lib):40s} min {ms[0]:8.2f} ms  med {med:8.2f} ms  mean {mean:8.3f} ms -> {a.batch * a.steps / mean * 1e3:.4e} steps/s   accepted/steps {check[lib]}")
