@@ -161,10 +161,15 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # ONGYM_BENCH_REHEARSE=1: rehearsal of the N-rank path on a box with fewer GPUs than ranks (ranks share the devices
+    # round-robin, the statistics reduction runs on gloo because RCCL refuses two ranks on one device). Never a result.
+    rehearse = os.environ.get("ONGYM_BENCH_REHEARSE") == "1"
+    device = local_rank % torch.cuda.device_count() if rehearse else local_rank
+    torch.cuda.set_device(device)
     from optical_networking_gym._dist import init_process_group, reduce_run_statistics, shard_bounds
     # under torch.distributed.run (RANK set) the process group is always created, also for one rank
-    dist = init_process_group("nccl", local_rank) if (world > 1 or "RANK" in os.environ) else None   # "nccl" = RCCL
+    backend = "gloo" if rehearse else "nccl"                                                          # "nccl" = RCCL
+    dist = init_process_group(backend, device) if (world > 1 or "RANK" in os.environ) else None
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -178,7 +183,7 @@ def main():
     global_batch = args.batch * world if args.scaling == "weak" else args.batch
     base, local_batch = shard_bounds(global_batch, rank, world)      # this rank's slice of the global replicas
     tables = build_tables(wl["topology"])
-    env = BatchedQRMSAEnv(tables=tables, modulations=jocn_modulations(), batch_size=local_batch, device=local_rank,
+    env = BatchedQRMSAEnv(tables=tables, modulations=jocn_modulations(), batch_size=local_batch, device=device,
                           num_spectrum_resources=wl["S"], capacity=wl["capacity"], episode_length=1000,
                           auto_reset=True, load=wl["load"], bit_rate_selection="discrete", bit_rates=wl["bit_rates"])
     env.seed(args.seed, replica_base=base)
@@ -213,7 +218,8 @@ def main():
     fields = ("total_steps", "total_accepted", "total_gn_evals", "total_interferer_terms", "total_paths_tried",
               "total_path_hops", "total_active_sum")
     delta = np.array([float(s1[f].sum() - s0[f].sum()) for f in fields], np.float64)
-    delta, dt_max, kernel_ms = reduce_run_statistics(delta, dt, kernel_ms, dist)   # the only collective (RCCL)
+    delta, dt_max, kernel_ms = reduce_run_statistics(delta, dt, kernel_ms, dist,     # the only collective (RCCL)
+                                                     device="cpu" if rehearse else "cuda")
     stats_sum = dict(zip(fields, delta))
     expected = float(global_batch) * args.steps * spl
     if int(stats_sum["total_steps"]) != int(expected):
@@ -272,6 +278,8 @@ def main():
         }
         # the timed state must be the loaded network, whatever the CLI said
         out["occupancy"] = env.occupancy()
+        if rehearse:
+            out["rehearsal"] = "ranks share GPUs, gloo reduction: plumbing check only, not a measurement"
         out["steady_state"] = bool(counters["mean_active_services"] >= 0.4 * wl["load"])
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(tables, wl, args.workload)

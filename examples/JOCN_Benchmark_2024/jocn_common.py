@@ -96,12 +96,14 @@ def run_sweep(topology, *, n_episodes, episode_length, replicas_per_point, point
     return [np.array(b) for b in blocking]
 
 
-def run_sweep_plugin(topology, heuristic, *, n_episodes, episode_length, points, seed, common, monitor_names):
+def run_sweep_plugin(topology, heuristic, *, n_episodes, episode_length, points, seed, common, monitor_names, k_paths=None):
     """The same sweep for a policy that exists only as a plugin (f(env) -> (action, flag, flag), e.g. heuristic 3 of the
     reference's graph_load.py): one device-backed QRMSAEnvWrapper per point, episodes in sequence, the reference's loop
     (graph_load.py:157-186) verbatim.  Orders of magnitude slower than the fused policies."""
     from optical_networking_gym.wrappers.qrmsa_gym import QRMSAEnvWrapper
     S = common.get("num_spectrum_resources", 320)
+    if k_paths is None:     # the routes the topology was built with (the CLI's -k)
+        k_paths = int(topology.graph.get("k_paths") or max(len(v) for v in topology.graph["ksp"].values()))
     blocking = []
     for i, (pt, name) in enumerate(zip(points, monitor_names)):
         kw = dict(common)
@@ -109,7 +111,7 @@ def run_sweep_plugin(topology, heuristic, *, n_episodes, episode_length, points,
         kw.pop("capacity", None)
         env = QRMSAEnvWrapper(topology=topology, seed=seed + i, allow_rejection=True, episode_length=episode_length,
                               bandwidth=S * 12.5e9, frequency_start=3e8 / 1565e-9, frequency_slot_bandwidth=12.5e9,
-                              k_paths=5, modulations_to_consider=6, gen_observation=False, **kw)
+                              k_paths=k_paths, modulations_to_consider=6, gen_observation=False, **kw)
         env.reset()
         os.makedirs(os.path.dirname(name) or ".", exist_ok=True)
         rates = []

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ONGYM_ABI_VERSION 1
+#define ONGYM_ABI_VERSION 2
 
 enum {
     ONGYM_OK = 0,
@@ -117,6 +117,12 @@ typedef struct ongym_config {
     /* observation() only (qrmsa.pyx:583-781): route lengths normalised by the min/max LINK length (:692-705) */
     const double *path_len_norm;          /* [n_paths] or NULL (ongym_observe then fails) */
     double max_bit_rate;                  /* max(bit_rates), qrmsa.pyx:679 */
+    /* 1: keep Service.service_id (qrmsa.pyx:1092) per running service, as cfg.defragmentation does.  calculate_osnr skips
+     * the running services whose id equals the evaluated service's (core/osnr.pyx:65, "quirk Q12"); ids are unique inside
+     * an episode, so this only shows after ongym_reset_episode_counters restarted them under services that keep running.
+     * Needed by ongym_reset_episode_counters; selects the id-tracking (slower) kernels. */
+    int32_t track_service_ids;
+    int32_t reserved_;
 } ongym_config;
 
 /* One service request; replaces the fields drawn in QRMSAEnv._next_service (qrmsa.pyx:1079-1101). */
@@ -221,6 +227,13 @@ int ongym_set_requests(ongym_env *env, const ongym_request *reqs, int64_t n_per_
 
 /* QRMSAEnv.reset (qrmsa.pyx:427-504) on the replicas with mask[r] != 0 (NULL = all). */
 int ongym_reset(ongym_env *env, const uint8_t *mask);
+
+/* QRMSAEnv.reset(options={"only_episode_counters": True}) (qrmsa.pyx:427-464) on the replicas with mask[r] != 0 (NULL =
+ * all): episode counters and histograms to zero, and — like the reference's `self._events = []` — the departure heap is
+ * dropped, so the services running at that moment never leave.  Grid, running services, totals, clock and the current
+ * request stay; no request is drawn.  Needs cfg.track_service_ids (ONGYM_E_STATE otherwise): service ids restart at 0 under
+ * services that keep running, and calculate_osnr identifies "self" by service id (core/osnr.pyx:65). */
+int ongym_reset_episode_counters(ongym_env *env, const uint8_t *mask);
 
 /* nsteps iterations of `action,_,_ = heuristic(env); env.step(action)` (graph_load.py:161-163) fused on device.
  * out: [nsteps][batch] records or NULL. */

@@ -46,6 +46,10 @@ struct DevEnv {
     // accepted service and one log10 per ~60 of them; both survive across launches so results do not depend on how
     // the steps are partitioned into launches. st.episode_osnr_sum is refreshed from them at every store.
     double osnr_flushed, osnr_prod;
+    // len(topology.graph["services"]) - episode_services_processed: 0 unless reset(options={"only_episode_counters": True})
+    // (qrmsa.pyx:461-464) zeroed the episode counter while the list of the episode's services kept growing; the JOCN
+    // drivers average Service.OSNR over that list (graph_load.py:181-185)
+    int64_t svc_list_extra;
     ongym_stats st;                          // LAST: its tail (the terminal-step snapshot) never enters LDS
 };
 // The kernels keep DevEnv up to (not including) st.last_episode_processed in LDS; the snapshot fields behind it are
@@ -61,6 +65,7 @@ struct Params {
     int bit_rate_mode, n_bit_rates, br_lo, br_hi;
     int measure_disruptions;
     int defragmentation, n_defrag_services;   // envs/qrmsa.pyx:233-234
+    int track_ids;      // Service.service_id (and OSNR) kept per record: defragmentation or cfg.track_service_ids
     int uniform_alpha;
     int rec32;          // record codec R32 in use (n_links <= 32, n_paths <= 512)
     int ase_shortcut;   // 1: every interferer term of the NLI sum is provably >= 0 (checked on the host at create)
@@ -99,9 +104,9 @@ struct Params {
     uint64_t *occ;
     uint32_t *svc_a, *svc_b;
     float *svc_r;
-    uint32_t *svc_q;   // Service.service_id per record  } only when defragmentation
+    uint32_t *svc_q;   // Service.service_id per record  } only when track_ids
     double *svc_o;     // Service.OSNR per record        }
-    ongym_move *move_log;   // [batch][ONGYM_MOVE_LOG] reallocations of the last step   } only when defragmentation
+    ongym_move *move_log;   // [batch][ONGYM_MOVE_LOG] reallocations of the last step   } only when track_ids
     int32_t *move_n;        // [batch] their count                                       }
     DevEnv *env;
     // request trace (req_mode == kReqTrace)
@@ -114,20 +119,20 @@ struct Params {
 // LDS carve-up (dynamic shared memory), 8-byte aligned pieces first
 //   DevEnv | lim f64[8] | rp f64[2] | phi f64[8] | nlic f64[8] | selfa f64[8] | nreq i32[8] |      (fixed size, constant addresses)
 //   occ u64[E*W] | lw f64[2E] (w1, w2 interleaved) | lcl f64[E] | lsc f64[E] | sa u32[C] | sb u32[C] | sr f32[C] | list u16[C] |
-//   (lim0 f64[8] when measure_disruptions or defragmentation) | (so f64[C] | sq u32[C] when defragmentation)
+//   (lim0 f64[8] when measure_disruptions or track_ids) | (so f64[C] | sq u32[C] when track_ids)
 // (DevEnv = its first kEnvHotBytes)
 // ---------------------------------------------------------------------------------------------------------------
 __host__ __device__ inline size_t lds_bytes(int n_links, int row_words, int capacity, int uniform_alpha,
-                                            int measure_disruptions, int defragmentation) {
+                                            int measure_disruptions, int track_ids) {
     size_t b = (size_t)n_links * row_words * 8 + (size_t)n_links * (uniform_alpha ? 16 : 32) + kEnvHotBytes;
     b += (size_t)capacity * 12 + 64 + 16 + 64 + 128 + 32 + (size_t)capacity * 2;
-    b += (measure_disruptions || defragmentation) ? 64 : 0;
-    b += defragmentation ? (size_t)capacity * 12 : 0;
+    b += (measure_disruptions || track_ids) ? 64 : 0;
+    b += track_ids ? (size_t)capacity * 12 : 0;
     return (b + 15) & ~(size_t)15;
 }
 
 __host__ __device__ inline size_t lds_bytes(const Params &P) {
-    return lds_bytes(P.n_links, P.row_words, P.capacity, P.uniform_alpha, P.measure_disruptions, P.defragmentation);
+    return lds_bytes(P.n_links, P.row_words, P.capacity, P.uniform_alpha, P.measure_disruptions, P.track_ids);
 }
 
 #ifdef ONGYM_STAMPS
@@ -177,6 +182,7 @@ struct Ctx {
     uint64_t pre_m0, pre_m1;
     double pre_ase, pre_w1;
     int active;        // running services (wave-uniform, mirrored to e->st.active at store time)
+    int skip_id;       // track_ids: service_id whose running namesakes the next GN evaluation skips (core/osnr.pyx:65); -1 none
     int lane_terms;    // per-lane interferer-link term counter (reduced once per launch)
     // sum of Service.OSNR = -10 log10(acc) over accepted services, kept as -10 log10 of a running PRODUCT of the acc's
     // (one multiply per step instead of one log10; folded into episode_osnr_sum by flush_osnr)
@@ -433,6 +439,10 @@ __device__ __forceinline__ int gn_build_list(Ctx &c, uint64_t cm0, uint64_t cm1)
         else {
             if (i0 < c.active) { const int pk = a0 & 0xFFFF; ov0 = ((G(P.path_mask)[2 * pk] & cm0) | (G(P.path_mask)[2 * pk + 1] & cm1)) != 0; }
             if (i1 < c.active) { const int pk = a1 & 0xFFFF; ov1 = ((G(P.path_mask)[2 * pk] & cm0) | (G(P.path_mask)[2 * pk + 1] & cm1)) != 0; }
+        }
+        if (P.track_ids && c.skip_id >= 0) {    // running services with the evaluated service's id are not interferers (quirk Q12)
+            if (i0 < c.active && c.sq[i0] == (uint32_t)c.skip_id) ov0 = false;
+            if (i1 < c.active && c.sq[i1] == (uint32_t)c.skip_id) ov1 = false;
         }
         const uint64_t bal0 = __ballot(ov0), bal1 = __ballot(ov1);
         const int n0 = __popcll((unsigned long long)bal0);
@@ -1065,6 +1075,7 @@ __device__ __forceinline__ void draw_next(Ctx &c) {
         e->st.episode_bit_rate_requested += (double)br;
     }
     wave_sync();
+    if (P.track_ids) c.skip_id = uniform_i32(e->cur_id);
 }
 
 // fold the running product into DevEnv.st.episode_osnr_sum (lane 0 only)
@@ -1090,6 +1101,7 @@ __device__ __forceinline__ void reset_env(Ctx &c) {
         s.episode_defrag_cycles = 0; s.episode_service_reallocations = 0;   // :438-439
         s.episode_osnr_sum = 0.0;
         e->osnr_flushed = 0.0; c.osnr_prod = 1.0;
+        e->svc_list_extra = 0;
         e->have_request = 0;
     }
     wave_sync();
@@ -1114,7 +1126,8 @@ __device__ __forceinline__ void snapshot_terminal(Ctx &c) {
         ? (s.episode_bit_rate_requested - s.episode_bit_rate_provisioned) / s.episode_bit_rate_requested : 0.0;
     for (int m = 0; m < 8; m++) o.last_modulation_hist[m] = s.episode_modulation_hist[m];
     // graph_load.py:181-185: mean of Service.OSNR over topology.graph["services"] (one entry per completed step)
-    o.last_mean_gsnr = s.episode_services_processed > 0 ? e->osnr_flushed / (double)s.episode_services_processed : 0.0;
+    o.last_mean_gsnr = s.episode_services_processed + e->svc_list_extra > 0
+        ? e->osnr_flushed / (double)(s.episode_services_processed + e->svc_list_extra) : 0.0;
     o.last_episode_disrupted = s.episode_disrupted_services;
     o.last_episode_defrag_cycles = s.episode_defrag_cycles;
     o.last_episode_service_reallocations = s.episode_service_reallocations;
@@ -1139,6 +1152,7 @@ __device__ __forceinline__ GnLin gn_service_acc(Ctx &c, int iy, int py, int sy, 
     for (int base = 0; base < c.active; base += kWave) {
         const int iz = base + c.lane;
         if (iz >= c.active || iz == iy) continue;
+        if (P.track_ids && c.sq[iz] == c.sq[iy]) continue;      // `rs.service_id != service.service_id`, core/osnr.pyx:65
         const uint32_t a = c.sa[iz], b = c.sb[iz];
         uint64_t m0, m1;
         if (R32) { m0 = a & (uint32_t)ym0; m1 = 0; }
@@ -1182,7 +1196,10 @@ __device__ __forceinline__ int below_minimum_osnr(const Ctx &c, double acc, int 
 
 template <bool R32>
 __device__ __forceinline__ int measure_disruptions(Ctx &c, uint64_t nm0, uint64_t nm1) {
+    const int keep_skip = c.skip_id;
+    c.skip_id = -1;                                          // a listing, not a GN sum
     const int L = gn_build_list<R32>(c, nm0, nm1);          // services on the new service's links
+    c.skip_id = keep_skip;
     int newly = 0;
     for (int j = 0; j < L; j++) {
         const int iy = c.list[j];
@@ -1317,7 +1334,7 @@ __device__ __forceinline__ void release_due_defrag(Ctx &c, float now) {
         }
         c.active = lastrec;
         wave_sync();
-        if (P.n_defrag_services == 0 || c.e->st.episode_services_processed % P.n_defrag_services == 0)
+        if (P.defragmentation && (P.n_defrag_services == 0 || c.e->st.episode_services_processed % P.n_defrag_services == 0))
             defragment<R32>(c, P.n_defrag_services);
     }
 }
@@ -1373,7 +1390,7 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
                 if (!rec) g[0] = -10.0 * log10(ch.g.ase + ch.g.nli);
                 e->osnr_flushed += g[0];
                 c.so[c.active] = g[0];
-                c.sq[c.active] = (uint32_t)(s.episode_services_processed - 1);   // Service.service_id (:1092)
+                c.sq[c.active] = (uint32_t)e->cur_id;   // Service.service_id (:1092), fixed when the request was drawn
             } else {
                 c.osnr_prod *= (ch.g.ase + ch.g.nli);
                 if (c.osnr_prod < 1e-250) flush_osnr(c);
@@ -1429,7 +1446,7 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
         // graph_load.py:181-185 reads Service.OSNR after the loop, i.e. after the departures (and moves) of this
         // _next_service
         if (DEFRAG && terminated)
-            P.env[c.replica].st.last_mean_gsnr = e->osnr_flushed / (double)(e->st.episode_services_processed - 1);
+            P.env[c.replica].st.last_mean_gsnr = e->osnr_flushed / (double)(e->st.episode_services_processed - 1 + e->svc_list_extra);
         if (rec) { rec->active = c.active; rec->terminated = (uint8_t)terminated; }
     }
     c.active_sum += c.active;
@@ -1796,7 +1813,7 @@ __device__ __forceinline__ void load_state(Ctx &c) {
     if (c.e->have_request) prefetch_first_path(c, c.e->cur_src, c.e->cur_dst);
     // per-replica acceptance limits in the linear domain (see qot_ok)
     if (c.lane < P.n_mods) c.lim[c.lane] = pow(10.0, -(P.mod_thr[c.lane] + c.e->margin) / 10.0);
-    if ((P.measure_disruptions || P.defragmentation) && c.lane < P.n_mods) c.lim0[c.lane] = pow(10.0, -P.mod_thr[c.lane] / 10.0);
+    if ((P.measure_disruptions || P.track_ids) && c.lane < P.n_mods) c.lim0[c.lane] = pow(10.0, -P.mod_thr[c.lane] / 10.0);
     if (c.lane < kMaxMods) c.phi[c.lane] = c.lane < P.n_mods ? P.mod_phi53[c.lane] : 0.0;
     if (c.lane == 0) { c.rp[0] = 1.0 / c.e->launch_power; c.rp[1] = c.e->launch_power * c.e->launch_power; }
     // slots needed by the current request (kept in LDS between requests, recomputed on load)
@@ -1810,8 +1827,9 @@ __device__ __forceinline__ void load_state(Ctx &c) {
     }
     size_t off = (size_t)c.replica * P.capacity;
     for (int i = c.lane; i < c.active; i += kWave) { c.sa[i] = P.svc_a[off + i]; c.sb[i] = P.svc_b[off + i]; c.sr[i] = P.svc_r[off + i]; }
-    if (P.defragmentation)
+    if (P.track_ids)
         for (int i = c.lane; i < c.active; i += kWave) { c.sq[i] = P.svc_q[off + i]; c.so[i] = P.svc_o[off + i]; }
+    c.skip_id = (P.track_ids && c.e->have_request) ? c.e->cur_id : -1;
     wave_sync();
 }
 
@@ -1840,7 +1858,7 @@ __device__ __forceinline__ void store_state(Ctx &c) {
     for (int i = c.lane; i < words; i += kWave) g[i] = c.occ[i];
     size_t off = (size_t)c.replica * P.capacity;
     for (int i = c.lane; i < c.active; i += kWave) { P.svc_a[off + i] = c.sa[i]; P.svc_b[off + i] = c.sb[i]; P.svc_r[off + i] = c.sr[i]; }
-    if (P.defragmentation)
+    if (P.track_ids)
         for (int i = c.lane; i < c.active; i += kWave) { P.svc_q[off + i] = c.sq[i]; P.svc_o[off + i] = c.so[i]; }
 }
 

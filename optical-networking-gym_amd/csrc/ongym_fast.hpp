@@ -638,7 +638,8 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                 so.last_episode_bit_rate_blocking_rate = s.episode_bit_rate_requested > 0
                     ? (s.episode_bit_rate_requested - s.episode_bit_rate_provisioned) / s.episode_bit_rate_requested : 0.0;
                 for (int m = 0; m < 8; m++) so.last_modulation_hist[m] = s.episode_modulation_hist[m];
-                so.last_mean_gsnr = s.episode_services_processed > 0 ? cold[4] / (double)s.episode_services_processed : 0.0;
+                so.last_mean_gsnr = s.episode_services_processed + ge->svc_list_extra > 0
+                    ? cold[4] / (double)(s.episode_services_processed + ge->svc_list_extra) : 0.0;
                 so.last_episode_disrupted = s.episode_disrupted_services;
                 so.last_episode_defrag_cycles = s.episode_defrag_cycles;
                 so.last_episode_service_reallocations = s.episode_service_reallocations;
@@ -685,6 +686,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             active = 0;
             epp = 0; erej = 0; cnt = 0;
             if (lane < 5) cold[lane] = 0.0;
+            if (lane == 0) ge->svc_list_extra = 0;
             osnr_prod = 1.0;
             wave_sync();
             pop_request();

@@ -146,6 +146,24 @@ __global__ void k_seed(Params P, uint64_t seed, uint64_t replica_base) {
     P.env[r].req_index = 0;
 }
 
+// reset(options={"only_episode_counters": True}) (qrmsa.pyx:427-464): the episode counters and histograms go to zero and the
+// departure heap is DROPPED (self._events = []): the services that are running stay in the network for good (release time
+// +inf; the 'disrupted' sign bit is kept).  Grid, running services, totals, clock and the current request are untouched.
+__global__ void k_reset_counters(Params P, const uint8_t *mask) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= P.batch || (mask && !mask[r])) return;
+    DevEnv &e = P.env[r];
+    ongym_stats &s = e.st;
+    e.svc_list_extra += s.episode_services_processed;   // len(graph["services"]) keeps growing from where it was
+    s.episode_bit_rate_requested = 0.0; s.episode_bit_rate_provisioned = 0.0;
+    s.episode_services_processed = 0; s.episode_services_accepted = 0;
+    s.episode_disrupted_services = 0; s.rejected = 0;
+    s.episode_defrag_cycles = 0; s.episode_service_reallocations = 0;
+    for (int m = 0; m < 8; m++) s.episode_modulation_hist[m] = 0;
+    float *rr = P.svc_r + (size_t)r * P.capacity;
+    for (int i = 0; i < s.active; i++) rr[i] = copysignf(INFINITY, rr[i]);
+}
+
 __global__ void k_rewind(Params P) {   // new trace: cursor back to 0
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= P.batch) return;
@@ -221,8 +239,8 @@ __global__ __launch_bounds__(64) void k_query(const Params *__restrict__ Pp, int
             o[i].nslots = (int16_t)rec_n<R32>(a, b); o[i].modulation = (int16_t)rec_mod<R32>(a, b);
             o[i].reserved = c.sr[i] < 0.f ? 1 : 0;   // 1: in the disrupted list (measure_disruptions)
             o[i].release_time = fabsf(c.sr[i]);
-            o[i].service_id = P.defragmentation ? (int32_t)c.sq[i] : -1; o[i].pad_ = 0;
-            o[i].osnr = P.defragmentation ? c.so[i] : 0.0;
+            o[i].service_id = P.track_ids ? (int32_t)c.sq[i] : -1; o[i].pad_ = 0;
+            o[i].osnr = P.track_ids ? c.so[i] : 0.0;
         }
     } else if (what == kQCandidates) {  // _get_candidates on a caller-supplied row: path = total_slots, n = nslots
         const int total = path;
@@ -275,6 +293,7 @@ struct ongym_env {
     bool has_source = false;
     bool fast_ok = false;           // the configuration is eligible for k_fast (see fast_eligible)
     bool fast_m64 = false;
+    int fast_waves = 4;             // waves per SIMD of the k_fast instantiation that runs (register budget 512 / waves)
     bool trace_used = false;        // a replayed trace may have left records the lean codec cannot hold
     size_t fast_lds = 0;
 };
@@ -289,6 +308,19 @@ struct ongym_env {
     } while (0)
 
 static std::string g_create_error;
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-kernel, process-wide setting: keep the largest request ever made
+// (an environment with a smaller LDS block must not lower the limit under one created earlier) and only ever raise it.
+#include <map>
+static hipError_t raise_lds_limit(const void *kernel, size_t bytes) {
+    static std::map<const void *, size_t> limit;
+    if (bytes <= 64 * 1024) return hipSuccess;        // the default limit covers it
+    size_t &cur = limit[kernel];
+    if (bytes <= cur) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) cur = bytes;
+    return e;
+}
 
 static int push_params(ongym_env *env) {
     HIP_TRY(env, hipMemcpyAsync(env->d_P, &env->P, sizeof(Params), hipMemcpyHostToDevice, env->stream));
@@ -363,6 +395,7 @@ static int build(ongym_env *env, const ongym_config *c) {
     P.req_mode = kReqNone;
     P.measure_disruptions = c->measure_disruptions ? 1 : 0;
     P.defragmentation = c->defragmentation ? 1 : 0;
+    P.track_ids = (c->defragmentation || c->track_service_ids) ? 1 : 0;
     P.n_defrag_services = c->n_defrag_services;
     if (c->defragmentation && c->n_defrag_services < 0) return fail_arg(env, "n_defrag_services must be >= 0");
     P.f0 = c->frequency_start; P.slot_bw = c->slot_bandwidth; P.channel_width = c->channel_width;
@@ -388,6 +421,7 @@ static int build(ongym_env *env, const ongym_config *c) {
     P.uniform_alpha = uniform ? 1 : 0;
     if (c->measure_disruptions && !uniform) return fail_arg(env, "measure_disruptions needs uniform attenuation", ONGYM_E_LIMIT);
     if (c->defragmentation && !uniform) return fail_arg(env, "defragmentation needs uniform attenuation", ONGYM_E_LIMIT);
+    if (c->track_service_ids && !uniform) return fail_arg(env, "track_service_ids needs uniform attenuation", ONGYM_E_LIMIT);
     P.rec32 = (E <= 32 && NP <= 512 && c->n_slots <= 1023) ? 1 : 0;
     P.alpha0_cl = cl[0];
     std::vector<uint64_t> mask((size_t)NP * 2, 0);
@@ -517,7 +551,7 @@ static int build(ongym_env *env, const ongym_config *c) {
 
     // ---- lean first-fit kernel (ongym_fast.hpp): eligibility and its two extra tables ----
     {
-        bool ok = uniform && P.ase_shortcut && !P.defragmentation && !P.measure_disruptions && c->bit_rate_mode == 0 &&
+        bool ok = uniform && P.ase_shortcut && !P.track_ids && !P.measure_disruptions && c->bit_rate_mode == 0 &&
                   c->n_bit_rates <= 8 && E <= 52 && N <= 64 && P.tab_stride < kTabPitch && !host_tab.empty();
         const char *force = std::getenv("ONGYM_FORCE_GENERIC");
         if (force && force[0] == '1') ok = false;
@@ -551,6 +585,10 @@ static int build(ongym_env *env, const ongym_config *c) {
                 }
             if ((rc = upload(env, t2.data(), t2.size(), &P.pair_tab2k))) return rc;
             env->fast_ok = true; env->fast_m64 = m64; env->fast_lds = flds;
+            // gfx950 hands out LDS in 1280-byte granules (160 KiB / 128; measured: 8160 B per workgroup gave 18 workgroups per
+            // CU, 7648 B gave 20): pick the instantiation whose register budget matches the replicas the LDS admits
+            const size_t granule = 1280, per_cu = (160 * 1024) / (((flds + granule - 1) / granule) * granule);
+            env->fast_waves = m64 ? 3 : (per_cu >= 17 ? 5 : 4);
         }
     }
 
@@ -561,7 +599,7 @@ static int build(ongym_env *env, const ongym_config *c) {
     if ((rc = dev_alloc(env, B * c->capacity, &P.svc_b, true))) return rc;
     if ((rc = dev_alloc(env, B * c->capacity, &P.svc_r, true))) return rc;
     P.svc_q = nullptr; P.svc_o = nullptr; P.move_log = nullptr; P.move_n = nullptr;
-    if (P.defragmentation) {
+    if (P.track_ids) {
         if ((rc = dev_alloc(env, B * c->capacity, &P.svc_q, true))) return rc;
         if ((rc = dev_alloc(env, B * c->capacity, &P.svc_o, true))) return rc;
         if ((rc = dev_alloc(env, B * ONGYM_MOVE_LOG, &P.move_log, true))) return rc;
@@ -595,14 +633,14 @@ static int build(ongym_env *env, const ongym_config *c) {
     env->lds = lds_bytes(P);
     if (env->lds > 64 * 1024) {
         if (env->lds > 160 * 1024) return fail_arg(env, "state does not fit the 160 KiB LDS: lower capacity", ONGYM_E_LIMIT);
-#define ONGYM_SET_LDS(K) HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->lds))
+#define ONGYM_SET_LDS(K) HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&K), env->lds))
         ONGYM_SET_LDS((k_run<true, true, 4, 0>)); ONGYM_SET_LDS((k_run<true, false, 4, 0>));
         ONGYM_SET_LDS((k_run<false, true, 4, 0>)); ONGYM_SET_LDS((k_run<false, false, 4, 0>));
         ONGYM_SET_LDS((k_run<true, true, 4, 1>)); ONGYM_SET_LDS((k_run<true, false, 4, 1>));
         ONGYM_SET_LDS((k_run<false, true, 4, 1>)); ONGYM_SET_LDS((k_run<false, false, 4, 1>));
         ONGYM_SET_LDS((k_run<true, true, 4, kPolicyMisc>)); ONGYM_SET_LDS((k_run<true, false, 4, kPolicyMisc>));
         ONGYM_SET_LDS((k_run<false, true, 4, kPolicyMisc>)); ONGYM_SET_LDS((k_run<false, false, 4, kPolicyMisc>));
-        if (P.defragmentation) {
+        if (P.track_ids) {
             ONGYM_SET_LDS((k_run<true, true, 4, 0, true>)); ONGYM_SET_LDS((k_run<true, false, 4, 0, true>));
             ONGYM_SET_LDS((k_run<true, true, 4, 1, true>)); ONGYM_SET_LDS((k_run<true, false, 4, 1, true>));
             ONGYM_SET_LDS((k_run<true, true, 4, kPolicyMisc, true>)); ONGYM_SET_LDS((k_run<true, false, 4, kPolicyMisc, true>));
@@ -615,8 +653,9 @@ static int build(ongym_env *env, const ongym_config *c) {
 #undef ONGYM_SET_LDS
     }
     if (env->fast_ok && env->fast_lds > 64 * 1024) {
-#define ONGYM_SET_FLDS(K) HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->fast_lds))
+#define ONGYM_SET_FLDS(K) HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&K), env->fast_lds))
         ONGYM_SET_FLDS((k_fast<false, false, 2, 4>)); ONGYM_SET_FLDS((k_fast<false, true, 2, 4>));
+        ONGYM_SET_FLDS((k_fast<false, false, 2, 5>)); ONGYM_SET_FLDS((k_fast<false, true, 2, 5>));
         ONGYM_SET_FLDS((k_fast<true, false, 4, 3>)); ONGYM_SET_FLDS((k_fast<true, true, 4, 3>));
 #undef ONGYM_SET_FLDS
     }
@@ -708,7 +747,7 @@ int ongym_query_occupancy(ongym_env *env, int32_t *blocks_per_cu, int32_t *lds_b
     const bool lean = env->fast_ok && !env->trace_used && env->P.req_mode == kReqRng;
     if (lean) {
         if (env->fast_m64) HIP_TRY(env, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<true, false, 4, 3>, 64, env->fast_lds));
-        else if (env->fast_lds <= 8192) HIP_TRY(env, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<false, false, 2, 5>, 64, env->fast_lds));
+        else if (env->fast_waves == 5) HIP_TRY(env, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<false, false, 2, 5>, 64, env->fast_lds));
         else HIP_TRY(env, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<false, false, 2, 4>, 64, env->fast_lds));
         *lds_bytes = (int32_t)env->fast_lds;
     } else {
@@ -798,6 +837,28 @@ int ongym_reset(ongym_env *env, const uint8_t *mask) {
     return ONGYM_OK;
 }
 
+int ongym_reset_episode_counters(ongym_env *env, const uint8_t *mask) {
+    if (!env) return ONGYM_E_ARG;
+    if (!env->P.track_ids) {
+        env->err = "ongym_reset_episode_counters needs cfg.track_service_ids (service ids restart under running services, "
+                   "and calculate_osnr skips interferers by service id)";
+        return ONGYM_E_STATE;
+    }
+    HIP_TRY(env, hipSetDevice(env->cfg.device));
+    const uint8_t *dmask = nullptr;
+    if (mask) {
+        if (env->cfg.io_device) dmask = mask;
+        else {
+            HIP_TRY(env, hipMemcpyAsync(env->d_mask, mask, (size_t)env->P.batch, hipMemcpyHostToDevice, env->stream));
+            dmask = env->d_mask;
+        }
+    }
+    int threads = 64, blocks = (env->P.batch + threads - 1) / threads;
+    hipLaunchKernelGGL(k_reset_counters, dim3(blocks), dim3(threads), 0, env->stream, env->P, dmask);
+    HIP_TRY(env, hipGetLastError());
+    return ONGYM_OK;
+}
+
 static size_t field_lds(const ongym_env *env) {   // k_observe / highest-SNR k_run: state block + Fx, Vw, xlist, needx
     const Params &P = env->P;
     return ((env->lds + ((size_t)2 * P.n_slots + 2) * (sizeof(double) + 2 + 1) + kMaxMods * kMaxRowWords * 8) + 15) & ~(size_t)15;
@@ -815,9 +876,8 @@ static int launch_run(ongym_env *env, int mode, int policy, int nsteps, const in
         if (d_out) hipLaunchKernelGGL((k_fast<M64, true, ENT, WAVES>), grid, block, env->fast_lds, env->stream, env->d_P, nsteps, d_out); \
         else hipLaunchKernelGGL((k_fast<M64, false, ENT, WAVES>), grid, block, env->fast_lds, env->stream, env->d_P, nsteps, d_out);      \
     } while (0)
-        static const bool four_waves = [] { const char *v = std::getenv("ONGYM_FAST_WAVES"); return v && v[0] == '4'; }();   // experiment switch
         if (env->fast_m64) ONGYM_LAUNCH_FAST(true, 4, 3);
-        else if (env->fast_lds <= 8192 && !four_waves) ONGYM_LAUNCH_FAST(false, 2, 5);
+        else if (env->fast_waves == 5) ONGYM_LAUNCH_FAST(false, 2, 5);
         else ONGYM_LAUNCH_FAST(false, 2, 4);
 #undef ONGYM_LAUNCH_FAST
         HIP_TRY(env, hipGetLastError());
@@ -828,18 +888,18 @@ static int launch_run(ongym_env *env, int mode, int policy, int nsteps, const in
     if (policy == ONGYM_POLICY_HIGHEST_SNR) {
         if (!env->P.uniform_alpha) return fail_arg(env, "the highest-SNR policy needs uniform attenuation", ONGYM_E_LIMIT);
         if (field_lds(env) > 64 * 1024) {
-            HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_run<true, true, 4, ONGYM_POLICY_HIGHEST_SNR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)field_lds(env)));
-            HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_run<true, false, 4, ONGYM_POLICY_HIGHEST_SNR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)field_lds(env)));
+            HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<true, true, 4, ONGYM_POLICY_HIGHEST_SNR>), field_lds(env)));
+            HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<true, false, 4, ONGYM_POLICY_HIGHEST_SNR>), field_lds(env)));
         }
     }
 #define ONGYM_LAUNCH_DEFRAG(R, POL, LDS)                                                                           \
     hipLaunchKernelGGL((k_run<true, R, 4, POL, true>), grid, block, LDS, env->stream, env->d_P, mode, nsteps,      \
                        d_actions, d_act_out, d_flag_out, d_out, policy)
-    if (env->P.defragmentation) {   // defragmentation (needs uniform attenuation, checked at create): own instantiations
+    if (env->P.track_ids) {   // defragmentation / service-id tracking (uniform attenuation, checked at create): own instantiations
         if (policy == ONGYM_POLICY_HIGHEST_SNR) {
             if (field_lds(env) > 64 * 1024) {
-                HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_run<true, true, 4, ONGYM_POLICY_HIGHEST_SNR, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)field_lds(env)));
-                HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_run<true, false, 4, ONGYM_POLICY_HIGHEST_SNR, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)field_lds(env)));
+                HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<true, true, 4, ONGYM_POLICY_HIGHEST_SNR, true>), field_lds(env)));
+                HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<true, false, 4, ONGYM_POLICY_HIGHEST_SNR, true>), field_lds(env)));
             }
             if (env->P.rec32) ONGYM_LAUNCH_DEFRAG(true, ONGYM_POLICY_HIGHEST_SNR, field_lds(env));
             else ONGYM_LAUNCH_DEFRAG(false, ONGYM_POLICY_HIGHEST_SNR, field_lds(env));
@@ -942,8 +1002,8 @@ int ongym_observe(ongym_env *env, float *obs, uint8_t *mask) {
     const size_t B = (size_t)P.batch;
     const size_t lds = field_lds(env);
     if (lds > 64 * 1024) {
-        HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_observe<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(env, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_observe<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_observe<true>), lds));
+        HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_observe<false>), lds));
     }
     float *d_obs = obs; uint8_t *d_mask = mask;
     if (!env->cfg.io_device) {

@@ -12,7 +12,7 @@ import numpy as np
 
 from ._tables import StaticTables, cumulative, modulation_arrays
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(os.path.dirname(PKG_DIR), "csrc")
 HIP_LIB_PATH = os.path.join(CSRC_DIR, "libongym_hip.so")
@@ -45,6 +45,7 @@ class OngymConfig(C.Structure):
         ("node_cum", _f64p),
         ("replica_launch_power_w", _f64p), ("replica_load", _f64p), ("replica_margin", _f64p),
         ("path_len_norm", _f64p), ("max_bit_rate", C.c_double),
+        ("track_service_ids", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -95,7 +96,7 @@ class ConfigHolder:
                  defragmentation: bool = False, n_defrag_services: int = 0,
                  replica_launch_power_dbm: Optional[Sequence[float]] = None,
                  replica_load: Optional[Sequence[float]] = None,
-                 replica_margin: Optional[Sequence[float]] = None):
+                 replica_margin: Optional[Sequence[float]] = None, track_service_ids: bool = False):
         if capacity % 64 or capacity <= 0:
             raise ValueError("capacity must be a positive multiple of 64")
         if load <= 0 or mean_service_holding_time <= 0:
@@ -134,6 +135,7 @@ class ConfigHolder:
         c.device, c.io_device = int(device), int(bool(io_device))
         c.measure_disruptions = int(bool(measure_disruptions))
         c.defragmentation, c.n_defrag_services = int(bool(defragmentation)), int(n_defrag_services)
+        c.track_service_ids = int(bool(track_service_ids))
         c.frequency_start, c.slot_bandwidth = float(frequency_start), float(frequency_slot_bandwidth)
         c.channel_width = float(channel_width)
         c.launch_power_w = 10 ** ((float(launch_power_dbm) - 30) / 10)  # qrmsa.pyx:288
@@ -184,6 +186,7 @@ def _declare(lib):
     lib.ongym_seed_base.argtypes = [vp, C.c_uint64, C.c_uint64]
     lib.ongym_set_requests.argtypes = [vp, vp, C.c_int64]
     lib.ongym_reset.argtypes = [vp, vp]
+    lib.ongym_reset_episode_counters.argtypes = [vp, vp]
     lib.ongym_step_policy.argtypes = [vp, C.c_int32, C.c_int32, vp]
     lib.ongym_step_actions.argtypes = [vp, vp, vp]
     lib.ongym_policy_actions.argtypes = [vp, C.c_int32, vp, vp]
@@ -206,7 +209,7 @@ def _declare(lib):
     lib.ongym_last_error.restype = C.c_char_p
     lib.ongym_abi_version.argtypes = []
     lib.ongym_sizeof.argtypes = [C.c_int32]
-    for name in ("ongym_create", "ongym_seed", "ongym_seed_base", "ongym_set_requests", "ongym_reset", "ongym_step_policy",
+    for name in ("ongym_create", "ongym_seed", "ongym_seed_base", "ongym_set_requests", "ongym_reset", "ongym_reset_episode_counters", "ongym_step_policy",
                  "ongym_step_actions", "ongym_policy_actions", "ongym_observe", "ongym_query_available", "ongym_query_gsnr", "ongym_query_gsnr_many", "ongym_query_moves",
                  "ongym_query_grid", "ongym_query_services", "ongym_query_request", "ongym_stats_get", "ongym_sync",
                  "ongym_abi_version", "ongym_sizeof", "ongym_query_candidates", "ongym_query_path_free", "ongym_observe", "ongym_query_occupancy"):
@@ -214,7 +217,7 @@ def _declare(lib):
 
 
 EXPORTED_SYMBOLS = (
-    "ongym_create", "ongym_destroy", "ongym_seed", "ongym_seed_base", "ongym_set_requests", "ongym_reset", "ongym_step_policy",
+    "ongym_create", "ongym_destroy", "ongym_seed", "ongym_seed_base", "ongym_set_requests", "ongym_reset", "ongym_reset_episode_counters", "ongym_step_policy",
     "ongym_step_actions", "ongym_policy_actions", "ongym_observe", "ongym_query_available", "ongym_query_gsnr", "ongym_query_gsnr_many", "ongym_query_moves", "ongym_query_grid",
     "ongym_query_services", "ongym_query_request", "ongym_query_candidates", "ongym_query_path_free",
     "ongym_stats_get", "ongym_sync", "ongym_last_kernel_ms", "ongym_query_occupancy",

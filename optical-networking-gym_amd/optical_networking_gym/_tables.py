@@ -93,6 +93,17 @@ class StaticTables:
             path_length=path_length, path_nodes=path_nodes, link_nodes=link_nodes, link_length=link_length,
             link_nspans=link_nspans, link_span_km=link_span_km, link_alpha=link_alpha, link_nf=link_nf)
 
+    def truncated(self, k_paths: int) -> "StaticTables":
+        """The same tables restricted to the first `k_paths` routes of every node pair (path ids and per-path arrays are
+        kept, so ids stay those of the topology's `Path` objects)."""
+        k_paths = int(k_paths)
+        if k_paths == self.k_paths:
+            return self
+        if not 0 < k_paths < self.k_paths:
+            raise ValueError(f"k_paths={k_paths} outside 1..{self.k_paths}")
+        from dataclasses import replace
+        return replace(self, k_paths=k_paths, pair_paths=np.ascontiguousarray(self.pair_paths[:, :, :k_paths]))
+
     @staticmethod
     def from_golden(tables: dict) -> "StaticTables":
         """Build from a `tests/golden/tables_*.json`-shaped dict (exported from the reference's get_topology)."""

@@ -108,6 +108,16 @@ class BatchedQRMSAEnv:
                 raise ValueError("mask must have one entry per replica")
         self._check(self.lib.ongym_reset(self._h, mask.ctypes.data if mask is not None else None), "ongym_reset")
 
+    def reset_episode_counters(self, mask: Optional[np.ndarray] = None):
+        """`reset(options={"only_episode_counters": True})` of the reference (qrmsa.pyx:427-464) per replica: episode counters
+        and histograms to zero, the departure heap dropped (running services stay for good), nothing else touched."""
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, np.uint8)
+            if mask.shape != (self.batch_size,):
+                raise ValueError("mask must have one entry per replica")
+        self._check(self.lib.ongym_reset_episode_counters(self._h, mask.ctypes.data if mask is not None else None),
+                    "ongym_reset_episode_counters")
+
     def step_policy(self, nsteps: int = 1, record: bool = True, policy: int = nat.POLICY_FIRST_FIT):
         """`nsteps` x {first-fit heuristic; step}. Returns STEP_DTYPE [nsteps, batch] when `record`, else None."""
         out = np.zeros((nsteps, self.batch_size), nat.STEP_DTYPE) if record else None

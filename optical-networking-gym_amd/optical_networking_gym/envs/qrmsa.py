@@ -12,8 +12,11 @@ heuristics; batch-scale use goes through `envs.batched.BatchedQRMSAEnv`.
 
 `gen_observation=True` returns the device-computed observation vector and action mask (`ongym_observe`).
 `measure_disruptions=True` counts disrupted services on device.
+`defragmentation=True` runs the reference's defragment() on device and replays its moves onto the `Service` objects.
 `bands` reproduces quirk Q9 (one slot per service); `file_name` writes the per-service CSV from the step records.
-Not covered yet (raise NotImplementedError rather than silently differ): `defragmentation`.
+`reset(options={"only_episode_counters": True})` is the reference's counters-only reset (qrmsa.pyx:427-464).
+A `k_paths` below the topology's k restricts routes, action space and device tables to the first `k_paths` routes of every
+pair; a larger one raises (the reference would index past its route lists).
 """
 from __future__ import annotations
 
@@ -104,6 +107,13 @@ class QRMSAEnv:
             raise ValueError("Seed must be an integer.")
         self.topology = topology
         self.k_shortest_paths = topology.graph["ksp"]          # KeyError 'ksp' on a bare graph, like the reference
+        topo_k = int(topology.graph.get("k_paths") or max((len(r) for r in self.k_shortest_paths.values()), default=0))
+        if int(k_paths) > topo_k:
+            raise ValueError(f"k_paths={k_paths} but the topology was built with {topo_k} routes per node pair")
+        if int(k_paths) < topo_k:
+            # the env's k_paths rules (action space, reject action, observation, qrmsa.pyx:319-321, 380, 696-700): plugins and
+            # the device then see only the first k_paths routes of every pair
+            self.k_shortest_paths = {pair: routes[:int(k_paths)] for pair, routes in self.k_shortest_paths.items()}
         self.modulations = topology.graph.get("modulations", [])
         self.num_spectrum_resources = int(num_spectrum_resources)
         self.episode_length = int(episode_length)
@@ -131,13 +141,13 @@ class QRMSAEnv:
         self.observation_space = _Box(low=-5, high=5, shape=(1 + 2 + self.k_paths + self.k_paths * self.modulations_to_consider * 12,),
                                       dtype=np.float32)
         self.reject_action = self.action_space.n - 1 if allow_rejection else 0
-        self._tables = StaticTables.from_topology(topology)
+        self._tables = StaticTables.from_topology(topology).truncated(self.k_paths)
         self._paths_by_id = {}
         for routes in self.k_shortest_paths.values():
             for p in routes:
                 self._paths_by_id[int(p.id)] = p
         self._nodes = list(topology.graph["node_indices"])
-        self._dev = BatchedQRMSAEnv(
+        dev_kw = dict(
             tables=self._tables, modulations=self.modulations, modulations_to_consider=modulations_to_consider,
             batch_size=1, capacity=capacity, auto_reset=False, device=device,
             num_spectrum_resources=num_spectrum_resources, episode_length=episode_length, load=load,
@@ -148,6 +158,17 @@ class QRMSAEnv:
             frequency_start=frequency_start, frequency_slot_bandwidth=frequency_slot_bandwidth, margin=margin,
             channel_width=self._slot_width, measure_disruptions=measure_disruptions,
             defragmentation=defragmentation, n_defrag_services=n_defrag_services)
+        # service ids are kept on device so that calculate_osnr's skip-by-service-id (core/osnr.pyx:65) is exact also after a
+        # counters-only reset; the id-tracking kernels need uniform attenuation (per-link attenuation: no ids, and the
+        # counters-only reset is then refused)
+        try:
+            self._dev = BatchedQRMSAEnv(track_service_ids=True, **dev_kw)
+            self._tracks_ids = True
+        except OngymError as exc:
+            if "uniform attenuation" not in str(exc):
+                raise
+            self._dev = BatchedQRMSAEnv(**dev_kw)
+            self._tracks_ids = False
         if requests is not None:
             self._dev.set_requests(requests)           # trace replay (parity tests)
         else:
@@ -225,8 +246,16 @@ class QRMSAEnv:
                 {"mask": np.zeros(self.action_space.n, np.uint8)})
 
     def reset(self, seed=None, options=None):
-        if options and options.get("only_episode_counters"):
-            raise NotImplementedError("only_episode_counters reset is not built yet")
+        if options is not None and options.get("only_episode_counters"):
+            # qrmsa.pyx:427-464: episode counters and histograms restart, `self._events = []` drops the departure heap (the
+            # running services stay for good), nothing else changes and no request is drawn; returns (observation, {})
+            if not self._tracks_ids:
+                raise NotImplementedError("only_episode_counters needs service ids on device (uniform attenuation)")
+            self._dev.reset_episode_counters()
+            self.max_modulation_idx = len(self.modulations) - 1
+            self._last_stats = self._dev.stats()[0]
+            obs, _ = self._blank_observation()
+            return obs, {}
         self._dev.reset()
         self.topology.graph["services"] = []
         self._accepted_by_id = {}

@@ -253,6 +253,17 @@ int orc_reset(orc_env *e) {
     return next_service(e);
 }
 
+/* reset(options={"only_episode_counters": True}) (envs/qrmsa.pyx:427-464): the first part of reset() only; note
+ * `self._events = []` — the departure heap is dropped, so the services running now are never released. */
+void orc_reset_counters(orc_env *e) {
+    e->ep_bit_rate_requested = 0.0; e->ep_bit_rate_provisioned = 0.0;
+    e->ep_processed = 0; e->ep_accepted = 0;
+    e->ep_disrupted_services = 0;
+    e->n_heap = 0; e->bl_reject = 0; e->max_mod_idx = e->cfg.n_mods - 1;
+    e->ep_defrag_cycles = 0; e->ep_reallocations = 0;
+    memset(e->ep_mod_hist, 0, sizeof(e->ep_mod_hist));
+}
+
 /* ---- get_available_slots (envs/qrmsa.pyx:1482-1512): product of the path's link rows --------------------------- */
 void orc_available(const orc_env *e, int path_id, int32_t *out) {
     int S = e->cfg.n_slots, H = e->cfg.max_hops, hops = e->path_hops[path_id];
@@ -357,7 +368,10 @@ static void gn_state(orc_env *e, int path_id, int slot, int n, double out[3], in
         }
     }
     if (count) e->total_gn++;
-    gn_core(e, path_id, center_freq(e, slot, n), e->cfg.slot_bandwidth * n, e->launch_power, -1, lists, counts, out,
+    /* the candidate is current_service: running services with ITS service_id are skipped (core/osnr.pyx:65, quirk Q12).
+     * Ids are unique among the running services of an episode, so this only ever matters after
+     * reset(options={"only_episode_counters": True}) restarted the ids under services that keep running. */
+    gn_core(e, path_id, center_freq(e, slot, n), e->cfg.slot_bandwidth * n, e->launch_power, e->cur.id, lists, counts, out,
             count ? &e->total_terms : 0);
 }
 void orc_gn(orc_env *e, int path_id, int slot, int n, double out[3]) { gn_state(e, path_id, slot, n, out, 0); }

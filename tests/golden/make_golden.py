@@ -663,6 +663,83 @@ TRAJ = {
 }
 
 
+
+# ----------------------------------------------------------------------------------------------------------------
+# reset(options={"only_episode_counters": True}) (qrmsa.pyx:427-464)
+# ----------------------------------------------------------------------------------------------------------------
+def run_counters_reset(tag="traj_nsfnet320_epreset", topo_name="nsfnet", seed=77, load=300, S=320, episode_length=400,
+                       before=150, after_full=120, k=5, bit_rates=(10, 40, 100, 400)):
+    """First fit for `before` steps, then the counters-only reset (the departure heap is dropped, the running services stay
+    for good), on to the end of that episode, a full reset and `after_full` more steps.  Per step: decision, counters of the
+    info dict; the terminal info; mean Service.OSNR over topology.graph["services"] at the terminal step."""
+    topo = load_topology(topo_name, k)
+    random.Random = seeded_random(seed)
+    try:
+        env = QRMSAEnvWrapper(
+            topology=topo, seed=10, allow_rejection=True, load=load, episode_length=episode_length,
+            num_spectrum_resources=S, launch_power_dbm=0.0, bandwidth=S * 12.5e9, frequency_start=3e8 / 1565e-9,
+            frequency_slot_bandwidth=12.5e9, bit_rate_selection="discrete", bit_rates=bit_rates, margin=0.0,
+            file_name="", measure_disruptions=False, k_paths=k, modulations_to_consider=6, defragmentation=False,
+            n_defrag_services=0, gen_observation=False)
+    finally:
+        random.Random = _OrigRandom
+    ff = H.heuristic_shortest_available_path_first_fit_best_modulation
+    reqs = [request_tuple(env)]
+    env.reset()
+    reqs.append(request_tuple(env))
+    steps, terminal = [], None
+    reset_at = -1
+
+    def one():
+        action, _, _ = ff(env)
+        _, reward, done, _, info = env.step(int(action))
+        svc = env.env.topology.graph["services"][-1]
+        steps.append(dict(action=int(action), accepted=int(svc.accepted), slot=int(info["chosen_slot"]),
+                          route=int(info["chosen_path_index"]), n=int(svc.number_slots), osnr=float(svc.OSNR),
+                          term=int(done), active=len(env.env.topology.graph["running_services"]),
+                          ep_acc=int(info["episode_services_accepted"]),
+                          ep_blk=float(info["episode_service_blocking_rate"]), blk=float(info["service_blocking_rate"]),
+                          ep_brblk=float(info["episode_bit_rate_blocking_rate"]), brblk=float(info["bit_rate_blocking_rate"])))
+        reqs.append(request_tuple(env))
+        return done, info
+
+    for _ in range(before):
+        done, _ = one()
+        assert not done
+    cur = env.env.current_service
+    obs, info = env.reset(options={"only_episode_counters": True})
+    assert info == {} and env.env.current_service is cur and not obs.any()
+    reset_at = len(steps)
+    done = False
+    while not done:
+        done, info = one()
+    svcs = env.env.topology.graph["services"]
+    terminal = {k_: (float(v) if not isinstance(v, (int, np.integer)) else int(v)) for k_, v in info.items() if k_ != "mask"}
+    terminal["mean_gsnr"] = float(sum(s.OSNR for s in svcs) / len(svcs))
+    terminal["n_services"] = len(svcs)
+    term_at = len(steps)
+    env.reset()
+    reqs.append(request_tuple(env))
+    for _ in range(after_full):
+        one()
+    reqs_a = np.array(reqs, dtype=np.float64)
+    out = dict(req_at=reqs_a[:, 0].astype(np.float32), req_ht=reqs_a[:, 1].astype(np.float32),
+               req_src=reqs_a[:, 2].astype(np.int32), req_dst=reqs_a[:, 3].astype(np.int32),
+               req_br=reqs_a[:, 4].astype(np.float32))
+    for key, dt in (("action", np.int32), ("accepted", np.uint8), ("slot", np.int16), ("route", np.int8), ("n", np.int16),
+                    ("osnr", np.float64), ("term", np.uint8), ("active", np.int32), ("ep_acc", np.int32),
+                    ("ep_blk", np.float64), ("blk", np.float64), ("ep_brblk", np.float64), ("brblk", np.float64)):
+        out["st_" + key] = np.array([s[key] for s in steps], dtype=dt)
+    np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **out)
+    json.dump(dict(tag=tag, topology=topo_name, seed=seed, load=load, S=S, episode_length=episode_length, before=before,
+                   reset_at=reset_at, term_at=term_at, after_full=after_full, bit_rates=list(bit_rates), k_paths=k,
+                   launch_power_dbm=0.0, margin=0.0, bit_rate_selection="discrete", frequency_start=3e8 / 1565e-9,
+                   slot_bw=12.5e9, mean_holding=10800.0, initial_resets=2, terminal_info=terminal, n_steps=len(steps)),
+              open(os.path.join(HERE, f"{tag}.json"), "w"), indent=1)
+    print(f"{tag}: {len(steps)} steps, counters reset after {reset_at}, terminated after {term_at}, "
+          f"active at the end of that episode {steps[term_at - 1]['active']}, terminal {terminal}")
+
+
 def main():
     want = sys.argv[1:]
     if not want or "tables" in want:
@@ -683,6 +760,8 @@ def main():
             run_decisions(tag, **kw)
     if not want or "linkstats_nsfnet320" in want:
         run_link_stats("linkstats_nsfnet320")
+    if not want or "traj_nsfnet320_epreset" in want:
+        run_counters_reset()
 
 
 if __name__ == "__main__":

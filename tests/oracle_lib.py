@@ -39,6 +39,8 @@ def lib():
         L.orc_seed.argtypes = [vp, C.c_uint64, C.c_uint64]
         L.orc_set_trace.argtypes = [vp, vp, C.c_int64]
         L.orc_reset.argtypes = [vp]
+        L.orc_reset_counters.argtypes = [vp]
+        L.orc_reset_counters.restype = None
         L.orc_number_slots.argtypes = [vp, C.c_float, C.c_int]
         L.orc_available.argtypes = [vp, C.c_int, vp]
         L.orc_candidates.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
@@ -89,6 +91,9 @@ class OracleEnv:
 
     def reset(self):
         return self.L.orc_reset(self.h)
+
+    def reset_counters(self):
+        self.L.orc_reset_counters(self.h)
 
     def number_slots(self, bit_rate: float, mod: int) -> int:
         return self.L.orc_number_slots(self.h, bit_rate, mod)

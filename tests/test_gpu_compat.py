@@ -254,3 +254,82 @@ def test_link_statistics_like_the_reference():
                 link = sim.topology[u][v]
                 have = [link["utilization"], link["external_fragmentation"], link["compactness"], link["last_update"]]
                 np.testing.assert_allclose(have, want, rtol=1e-12, atol=1e-15)
+
+
+def test_counters_only_reset_through_the_gym_surface():
+    """env.reset(options={"only_episode_counters": True}) (qrmsa.pyx:427-464) on the compatibility env, driven like the
+    reference run that produced tests/golden/traj_nsfnet320_epreset: same actions (including the one decision that only
+    comes out right when running services with the new request's service_id are skipped, core/osnr.pyx:65), the episode
+    then lasts episode_length steps, terminal info and mean GSNR over the un-cleared services list."""
+    meta, d = load_traj("traj_nsfnet320_epreset")
+    topology = get_topology(bundled_topology_path("nsfnet_chen.txt"), None, jocn_modulations(), 80, 0.2, 4.5, 5)
+    env = QRMSAEnvWrapper(topology=topology, seed=10, allow_rejection=True, load=meta["load"],
+                          episode_length=meta["episode_length"], num_spectrum_resources=meta["S"], launch_power_dbm=0.0,
+                          bandwidth=meta["S"] * 12.5e9, frequency_start=3e8 / 1565e-9, frequency_slot_bandwidth=12.5e9,
+                          bit_rate_selection="discrete", bit_rates=tuple(meta["bit_rates"]), margin=0.0, file_name="",
+                          measure_disruptions=False, k_paths=5, modulations_to_consider=6, defragmentation=False,
+                          n_defrag_services=0, gen_observation=False, requests=traj_requests(d))
+    env.reset()
+    ff = heuristic_shortest_available_path_first_fit_best_modulation
+    i = 0
+
+    def one():
+        nonlocal i
+        action, _, _ = ff(env)
+        assert action == d["st_action"][i], i
+        _, _, done, _, info = env.step(action)
+        assert done == bool(d["st_term"][i]) and info["episode_services_accepted"] == d["st_ep_acc"][i], i
+        assert info["episode_service_blocking_rate"] == pytest.approx(d["st_ep_blk"][i], rel=1e-12, abs=1e-15)
+        assert info["episode_bit_rate_blocking_rate"] == pytest.approx(d["st_ep_brblk"][i], rel=1e-12, abs=1e-15)
+        assert len(env.env.topology.graph["running_services"]) == d["st_active"][i]
+        i += 1
+        return done, info
+
+    for _ in range(meta["before"]):
+        one()
+    cur = env.env.current_service
+    obs, info = env.reset(options={"only_episode_counters": True})
+    assert info == {} and not obs.any() and env.env.current_service is cur
+    done = False
+    while not done:
+        done, info = one()
+    assert i == meta["term_at"]
+    ti = meta["terminal_info"]
+    for k in ("rejected", "episode_services_accepted", "modulation_2.0", "modulation_3.0", "modulation_4.0", "modulation_6.0"):
+        assert info[k] == ti[k], k
+    for k in ("service_blocking_rate", "episode_service_blocking_rate", "bit_rate_blocking_rate", "episode_bit_rate_blocking_rate"):
+        assert info[k] == pytest.approx(ti[k], rel=1e-12), k
+    services = env.env.topology.graph["services"]
+    assert len(services) == ti["n_services"]
+    assert sum(s.OSNR for s in services) / len(services) == pytest.approx(ti["mean_gsnr"], rel=1e-9)
+    env.reset()
+    for _ in range(meta["after_full"]):
+        one()
+
+
+def test_env_k_paths_below_the_topology_k():
+    """QRMSAEnv(topology built with k=5, k_paths=3): routes, action space, reject action and the device tables all use the
+    first three routes (a heuristic's reject action then IS the device's; ADVICE r1: a mismatch used to loop forever or
+    decode a reject as an allocation).  Decisions equal a topology built with k=3 outright."""
+    mods = jocn_modulations()
+    topo5 = get_topology(bundled_topology_path("nsfnet_chen.txt"), None, mods, 80, 0.2, 4.5, 5)
+    topo3 = get_topology(bundled_topology_path("nsfnet_chen.txt"), None, mods, 80, 0.2, 4.5, 3)
+    kw = dict(seed=3, allow_rejection=True, load=900, episode_length=400, num_spectrum_resources=160, launch_power_dbm=0.0,
+              bandwidth=160 * 12.5e9, frequency_start=3e8 / 1565e-9, frequency_slot_bandwidth=12.5e9,
+              bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), margin=0.0, file_name="", k_paths=3,
+              modulations_to_consider=6, gen_observation=False)
+    a, b = QRMSAEnvWrapper(topology=topo5, **kw), QRMSAEnvWrapper(topology=topo3, **kw)
+    assert a.env.action_space.n == b.env.action_space.n == 3 * 6 * 160 + 1 and a.env.reject_action == 3 * 6 * 160
+    assert all(len(r) == 3 for r in a.env.k_shortest_paths.values())
+    a.reset(); b.reset()
+    rejected = 0
+    for i in range(300):
+        fa = heuristic_shortest_available_path_first_fit_best_modulation(a)
+        fb = heuristic_shortest_available_path_first_fit_best_modulation_plugin(b)
+        assert fa == fb, i
+        rejected += fa[0] == a.env.reject_action
+        ra, rb = a.step(fa[0]), b.step(fb[0])
+        assert ra[1] == rb[1] and ra[2] == rb[2] and ra[4]["episode_services_accepted"] == rb[4]["episode_services_accepted"]
+    assert rejected > 5          # the reject action really went through step() (reward -6, next request drawn)
+    with pytest.raises(ValueError):
+        QRMSAEnvWrapper(topology=topo3, **dict(kw, k_paths=5))

@@ -243,6 +243,55 @@ def test_device_generator_continuous_bit_rates_vs_oracle():
         np.testing.assert_array_equal(env.grid(r), oracles[r].grid())
 
 
+def test_counters_only_reset_vs_reference_and_oracle():
+    """ongym_reset_episode_counters = reset(options={"only_episode_counters": True}) (qrmsa.pyx:427-464): replay of the
+    reference's captured run, then the same call in the middle of device-generated traffic vs the oracle, including replicas
+    that are NOT reset (mask).  Needs cfg.track_service_ids (the id-tracking kernels)."""
+    from test_oracle_golden import _epreset_checks
+    meta, d = load_traj("traj_nsfnet320_epreset")
+    with pytest.raises(OngymError):          # ids are needed (core/osnr.pyx:65 skips interferers by service id)
+        make_env(meta, auto_reset=False).reset_episode_counters()
+    env = make_env(meta, auto_reset=False, track_service_ids=True)
+    env.set_requests(traj_requests(d))
+    for _ in range(meta["initial_resets"]):
+        env.reset()
+    recs = env.step_policy(meta["reset_at"])[:, 0]
+    env.reset_episode_counters()
+    st0 = env.stats()[0]
+    assert st0["episode_services_processed"] == 0 and st0["episode_services_accepted"] == 0 and st0["active"] == recs["active"][-1]
+    recs = np.concatenate([recs, env.step_policy(meta["term_at"] - meta["reset_at"])[:, 0]])
+    st = env.stats()[0]
+    env.reset()
+    recs = np.concatenate([recs, env.step_policy(meta["after_full"])[:, 0]])
+    _epreset_checks(meta, d, recs, st, meta["reset_at"])
+    # device generator (lean kernel where eligible) vs oracle, counters reset on every second replica only
+    B, kw = 16, dict(modulations=jocn_modulations(), num_spectrum_resources=320, capacity=1024, episode_length=500,
+                     auto_reset=True, load=320, bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400))
+    holder = nat.ConfigHolder(golden_tables("nsfnet"), batch=B, **kw)
+    dev = BatchedQRMSAEnv(tables=golden_tables("nsfnet"), batch_size=B, track_service_ids=True, **kw)
+    dev.seed(31); dev.reset()
+    mask = (np.arange(B) % 2 == 0).astype(np.uint8)
+    got = [dev.step_policy(180)]
+    dev.reset_episode_counters(mask)
+    got.append(dev.step_policy(700))
+    got = np.concatenate(got)
+    sd = dev.stats()
+    for r in range(B):
+        o = OracleEnv(holder, replica=r); o.seed(31); o.reset()
+        want = [o.run_first_fit(180)]
+        if mask[r]:
+            o.reset_counters()
+        want.append(o.run_first_fit(700))
+        assert_records_equal(got[:, r], np.concatenate(want), f"replica {r}")
+        so = o.stats()
+        for f in ("episode_services_processed", "episode_services_accepted", "rejected", "episode_bit_rate_requested",
+                  "episode_bit_rate_provisioned", "bit_rate_requested", "active", "episodes_completed",
+                  "last_episode_accepted", "last_episode_service_blocking_rate"):
+            assert sd[r][f] == so[f], (r, f)
+        assert sd[r]["last_mean_gsnr"] == pytest.approx(so["last_mean_gsnr"], rel=1e-9)
+        np.testing.assert_array_equal(dev.grid(r), o.grid())
+
+
 def test_nonuniform_attenuation_vs_oracle():
     """per-link alpha (template path UNIFORM_ALPHA=false)."""
     import copy

@@ -275,3 +275,44 @@ def test_remaining_policies_decide_like_the_reference(tag):
             if not r["retry"]:
                 assert r["accepted"] == d["st_accepted"][row], row
     assert checked == len(names) * len(d["dec_" + meta["driver"]]) >= 750
+
+
+def _epreset_checks(meta, d, recs, stats_at_term, reset_counters_called_at):
+    n = meta["n_steps"]
+    for f, g in (("action", "st_action"), ("accepted", "st_accepted"), ("slot", "st_slot"), ("route", "st_route"),
+                 ("nslots", "st_n"), ("terminated", "st_term"), ("active", "st_active")):
+        assert np.array_equal(recs[f][:n].astype(np.int64), d[g].astype(np.int64)), f
+    np.testing.assert_allclose(recs["osnr"][:n], d["st_osnr"], rtol=1e-9)
+    assert reset_counters_called_at == meta["reset_at"]
+    ti = meta["terminal_info"]
+    assert int(stats_at_term["last_episode_accepted"]) == ti["episode_services_accepted"]
+    assert int(stats_at_term["last_rejected"]) == ti["rejected"]
+    for ours, ref in (("last_service_blocking_rate", "service_blocking_rate"),
+                      ("last_episode_service_blocking_rate", "episode_service_blocking_rate"),
+                      ("last_bit_rate_blocking_rate", "bit_rate_blocking_rate"),
+                      ("last_episode_bit_rate_blocking_rate", "episode_bit_rate_blocking_rate")):
+        assert stats_at_term[ours] == pytest.approx(ti[ref], rel=1e-12), ours
+    hist = [ti[f"modulation_{float(se)}"] for se in (1, 2, 3, 4, 5, 6)]
+    assert list(stats_at_term["last_modulation_hist"][:6]) == hist
+    assert stats_at_term["last_mean_gsnr"] == pytest.approx(ti["mean_gsnr"], rel=1e-9)
+
+
+def test_counters_only_reset_vs_reference():
+    """reset(options={"only_episode_counters": True}) (qrmsa.pyx:427-464): the episode counters restart, the departure heap is
+    dropped (the services running at that moment stay for good: the active count never falls below them again), the
+    episode then lasts episode_length steps, and mean Service.OSNR is taken over the whole services list."""
+    meta, d = load_traj("traj_nsfnet320_epreset")
+    env = OracleEnv(holder_for(meta, auto_reset=False))
+    env.set_trace(traj_requests(d))
+    for _ in range(meta["initial_resets"]):
+        env.reset()
+    recs = np.concatenate([env.run_first_fit(meta["reset_at"])])
+    env.reset_counters()
+    assert env.stats()["episode_services_processed"] == 0 and env.stats()["active"] == d["st_active"][meta["reset_at"] - 1]
+    recs = np.concatenate([recs, env.run_first_fit(meta["term_at"] - meta["reset_at"])])
+    assert recs["terminated"][-1] == 1 and recs["terminated"][:-1].sum() == 0
+    st = env.stats()
+    assert d["st_active"][meta["reset_at"]:meta["term_at"]].min() >= d["st_active"][meta["reset_at"] - 1] - 1
+    env.reset()
+    recs = np.concatenate([recs, env.run_first_fit(meta["after_full"])])
+    _epreset_checks(meta, d, recs, st, meta["reset_at"])
