@@ -122,7 +122,11 @@ typedef struct ongym_config {
      * an episode, so this only shows after ongym_reset_episode_counters restarted them under services that keep running.
      * Needed by ongym_reset_episode_counters; selects the id-tracking (slower) kernels. */
     int32_t track_service_ids;
-    int32_t reserved_;
+    /* modulations_to_consider (qrmsa.pyx:313): 0 or >= n_mods = all of them.  Below n_mods the action space shrinks to
+     * k_paths * n_mods_consider * n_slots + 1 and addresses the n_mods_consider formats at and below max_modulation_idx
+     * (action codec qrmsa.pyx:801-834, heuristics.py:36-54); ongym_observe then first finds max_modulation_idx like
+     * get_max_modulation_index (qrmsa.pyx:543-581) and reports that window (:712-717). */
+    int32_t n_mods_consider;
 } ongym_config;
 
 /* One service request; replaces the fields drawn in QRMSAEnv._next_service (qrmsa.pyx:1079-1101). */
@@ -195,6 +199,9 @@ typedef struct ongym_stats {
     int64_t total_active_sum;                   /* sum over steps of the running-service count after the step */
     double current_time;
     int32_t active, flags;
+    int32_t max_modulation_idx; /* QRMSAEnv.max_modulation_idx: n_mods-1 after reset (qrmsa.pyx:437), set by observation()'s
+                                   get_max_modulation_index (:543-581, 680); the action codec is relative to it */
+    int32_t reserved0_;
     /* snapshot taken at the last terminal step (what graph_load.py writes per episode). Kept LAST: the kernels hold only
      * the fields above in LDS and write these straight to memory. */
     int64_t last_episode_processed, last_episode_accepted, last_rejected;
@@ -244,10 +251,12 @@ int ongym_step_actions(ongym_env *env, const int32_t *actions, ongym_step_rec *o
 int ongym_policy_actions(ongym_env *env, int32_t policy, int32_t *actions, uint8_t *flags);
 
 /* QRMSAEnv.observation() (qrmsa.pyx:583-781, gen_observation=True) for the CURRENT request of every replica:
- * obs  float32 [batch][1 + 2 + k_paths + k_paths*n_mods*12]  (bit rate, src, dst, k route lengths, 12 features per
- *      (path, modulation) pair incl. the normalised GSNR of calculate_osnr_observation, core/osnr.pyx:259-369)
- * mask uint8   [batch][k_paths*n_mods*n_slots + 1]            (info['mask'], last entry = reject = 1)
- * Needs uniform attenuation, n_mods == modulations_to_consider and slot_bandwidth == channel_width*1e9. */
+ * obs  float32 [batch][1 + 2 + k_paths + k_paths*Mc*12]  (bit rate, src, dst, k route lengths, 12 features per (path,
+ *      modulation) pair incl. the normalised GSNR of calculate_osnr_observation, core/osnr.pyx:259-369)
+ * mask uint8   [batch][k_paths*Mc*n_slots + 1]            (info['mask'], last entry = reject = 1)
+ * Mc = cfg.n_mods_consider.  For Mc < n_mods the call first sets ongym_stats.max_modulation_idx like
+ * get_max_modulation_index (qrmsa.pyx:543-581) and describes the Mc formats at and below it.
+ * Needs uniform attenuation and slot_bandwidth == channel_width*1e9. */
 int ongym_observe(ongym_env *env, float *obs, uint8_t *mask);
 
 /* Plugin-API queries on one replica (host buffers always): */

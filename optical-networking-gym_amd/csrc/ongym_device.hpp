@@ -59,6 +59,7 @@ static_assert(offsetof(DevEnv, st) % 8 == 0, "DevEnv.st must be 8-byte aligned")
 
 struct Params {
     int n_nodes, n_links, n_paths, k_paths, max_hops, n_mods, n_slots;
+    int n_mods_consider;   // modulations_to_consider (envs/qrmsa.pyx:313), 1..n_mods: width of the action codec's format window
     int row_words;   // W  = ceil(S/64): words per link row in occ
     int ext_words;   // Wx = S/64 + 1  : words of the row extended by the virtual free slot S
     int batch, capacity, episode_length, auto_reset;
@@ -612,7 +613,10 @@ template <bool UNIFORM_ALPHA, bool R32>
 __device__ __forceinline__ void policy_first_fit(Ctx &c, int src, int dst, double launch_power, double margin,
                                                  Choice &ch) {
     const Params &P = c.P;
-    const int M = P.n_mods, S = P.n_slots, max_mod = M - 1;
+    // formats from max_modulation_idx down (heuristics.py:930); the action index is relative to it and uses the codec's
+    // window width (get_action_index, :36-54) — with modulations_to_consider < n_mods it can leave the window, exactly like
+    // the reference's (the step then decodes what the codec says, see k_run)
+    const int M = P.n_mods_consider, S = P.n_slots, max_mod = uniform_i32(c.e->st.max_modulation_idx);
     ch.action = P.k_paths * M * S; ch.route = -1; ch.mod = -1; ch.slot = -1; ch.n = 0; ch.hops = 0; ch.mylink = 0;
     ch.path = -1; ch.m0 = 0; ch.g.ase = ch.g.nli = 0.0;
     int bres = 0, bosnr = 0;
@@ -735,7 +739,7 @@ template <bool UNIFORM_ALPHA, bool R32>
 __device__ __forceinline__ int evaluate_action(Ctx &c, int src, int dst, double launch_power, double margin,
                                                int action, Choice &ch) {
     const Params &P = c.P;
-    const int M = P.n_mods, S = P.n_slots, max_mod = M - 1;
+    const int M = P.n_mods_consider, S = P.n_slots, max_mod = uniform_i32(c.e->st.max_modulation_idx);
     ch.action = action; ch.route = -1; ch.mod = -1; ch.slot = -1; ch.n = 0; ch.flags = 0; ch.hops = 0; ch.mylink = 0;
     ch.path = -1; ch.m0 = 0; ch.g.ase = ch.g.nli = 0.0;
     if (action == P.k_paths * M * S) return 1;
@@ -743,7 +747,9 @@ __device__ __forceinline__ int evaluate_action(Ctx &c, int src, int dst, double 
     int slot = action % S; int t = action / S;
     int r = t % M; t /= M;
     int route = t % P.k_paths;
-    int m = max_mod - r;   // allowed_mods = range(max_idx, max_idx-M, -1), max_idx = M-1 when gen_observation=False
+    // allowed_mods = range(max_idx, max_idx - M, -1) if max_idx > 1 else reversed(range(M))   (envs/qrmsa.pyx:821-825)
+    int m = max_mod > 1 ? max_mod - r : (M - 1) - r;
+    if (m < 0 || m >= P.n_mods) return 2;
     ch.route = route; ch.mod = m; ch.slot = slot;
     int path = G(P.pair_paths)[(src * P.n_nodes + dst) * P.k_paths + route];
     int n = c.nreq[m];
@@ -1099,6 +1105,7 @@ __device__ __forceinline__ void reset_env(Ctx &c) {
         s.bit_rate_requested = 0.0; s.bit_rate_provisioned = 0.0;   // :466-467
         s.disrupted_services = 0; s.episode_disrupted_services = 0;   // :432, 468-469
         s.episode_defrag_cycles = 0; s.episode_service_reallocations = 0;   // :438-439
+        s.max_modulation_idx = P.n_mods - 1;                                // :437
         s.episode_osnr_sum = 0.0;
         e->osnr_flushed = 0.0; c.osnr_prod = 1.0;
         e->svc_list_extra = 0;
@@ -1597,7 +1604,7 @@ template <bool R32>
 __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, uint16_t *xlist, uint8_t *needx,
                                             float *obs, uint8_t *mask) {
     const Params &P = c.P;
-    const int K = P.k_paths, M = P.n_mods, S = P.n_slots, N = P.n_nodes;
+    const int K = P.k_paths, Mall = P.n_mods, M = P.n_mods_consider, S = P.n_slots, N = P.n_nodes;
     const int nx = 2 * S + 1, W = P.row_words;
     const int obs_dim = 3 + K + K * M * 12;
     const long long nact = (long long)K * M * S + 1;
@@ -1615,6 +1622,44 @@ __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, ui
         obs[2] = (float)((double)dst / (double)(N - 1));
         mask[nact - 1] = 1;                                          // :766
     }
+    // ---- get_max_modulation_index (:543-581, called at :680): path-major, best format first; the first candidate whose
+    // calculate_osnr reaches minimum_osnr + margin fixes max_modulation_idx = max(its format, modulations_to_consider - 1).
+    // With modulations_to_consider == n_mods that is n_mods - 1 whatever the network holds, so the scan is skipped.
+    int max_idx = Mall - 1;
+    if (M < Mall) {
+        max_idx = M - 1;
+        bool found = false;
+        for (int k = 0; k < K && !found; k++) {
+            const int path = uniform_i32(G(P.pair_paths)[(src * N + dst) * K + k]);
+            if (path < 0) break;
+            PathRef p = load_path(c, path);
+            const uint64_t free_ext = path_free_ext(c, p);
+            build_field<R32>(c, p, free_ext, FieldLds{Fx, Vw, xlist, needx});
+            const double pw1 = G(P.path_w1)[path], pase = G(P.path_ase)[path];
+            for (int mi = 0; mi < Mall && !found; mi++) {
+                const int m = Mall - 1 - mi;
+                const int n = uniform_i32(c.nreq[m]);
+                if (n <= 0 || n > S) continue;
+                const double bw = P.slot_bw * n, lim = c.lim[m];
+                const double self = pw1 * G(P.self_asinh)[n], nlic = G(P.nli_coef)[n] * c.rp[1];
+                bool pass = false;
+                for (int i = 0; i < W; i++) {
+                    const uint64_t w = Vw[mi * kMaxRowWords + i];
+                    const int s0 = i * 64 + c.lane;
+                    if (((w >> c.lane) & 1ull) && s0 < S) {
+                        const double fc = P.f0 + (P.slot_bw * s0) + (P.slot_bw * (n / 2.0));
+                        const double acc = (bw * fc * pase) * c.rp[0] + nlic * (self + Fx[2 * s0 + n]);
+                        if (acc <= lim * (1.0 - 1e-9)) pass = true;                       // same decision as qot_ok
+                        else if (acc < lim * (1.0 + 1e-9)) pass |= 10.0 * log10(1.0 / acc) >= P.mod_thr[m] + e->margin;
+                    }
+                }
+                if (__ballot(pass)) { max_idx = max(m, M - 1); found = true; }
+            }
+        }
+    }
+    if (c.lane == 0) P.env[c.replica].st.max_modulation_idx = max_idx;     // the codec of the next step() is relative to it
+    // the window of formats the observation describes: modulations[start : start + M], best first (:712-717)
+    const int mod_start = max_idx <= 1 ? 0 : max(0, max_idx - (M - 1));
     for (int k = 0; k < K; k++) {
         const int path = G(P.pair_paths)[(src * N + dst) * K + k];
         float *frow = obs + 3 + K + k * M * 12;
@@ -1647,10 +1692,12 @@ __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, ui
         const double len2 = (double)wave_sum_i32(len2_l);
         // ---- interferer field F(x) at the needed centres + valid starts per modulation (shared builder)
         build_field<R32>(c, p, free_ext, FieldLds{Fx, Vw, xlist, needx});
-        // ---- per modulation, best first (mod_list = reversed(modulations[0:M]), :716-717)
+        // ---- per format of the window, best first (mod_list = reversed(modulations[start : start + M]), :716-717); the field
+        // builder numbers its valid-start rows from the best of ALL formats: row fi = n_mods - 1 - m
         const double pw1 = G(P.path_w1)[path], pase = G(P.path_ase)[path];
         for (int mi = 0; mi < M; mi++) {
-            const int m = M - 1 - mi;
+            const int m = mod_start + M - 1 - mi;
+            const int fi = Mall - 1 - m;
             const int n = uniform_i32(c.nreq[m]);
             float *f12 = frow + mi * 12;
             uint8_t *mm = mrow + (long long)mi * S;
@@ -1664,7 +1711,7 @@ __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, ui
             int cnt_l = 0, sum_l = 0, sum2_l = 0, max_l = 0;
             double os_l = 0.0, os2_l = 0.0, omax_l = -1e300;
             for (int i = 0; i < W; i++) {
-                const uint64_t w = Vw[mi * kMaxRowWords + i];   // valid starts of _get_candidates (:590)
+                const uint64_t w = Vw[fi * kMaxRowWords + i];   // valid starts of _get_candidates (:590)
                 const int s = i * 64 + c.lane;
                 const bool valid = ((w >> c.lane) & 1ull) && s < S;
                 uint8_t bit = 0;

@@ -75,6 +75,11 @@ __global__ __launch_bounds__(64, WAVES) void k_run(const Params *__restrict__ Pp
             else if (POLICY == kPolicyMisc) policy_misc<UA, R32>(c, policy_id, src, dst, mg, ch);
             else policy_first_fit<UA, R32>(c, src, dst, lp, mg, ch);
             outcome = ch.route >= 0 ? (ch.busy ? 2 : 0) : 1;
+            // modulations_to_consider < n_mods: `env.step(action)` decodes the heuristic's action index with the window codec
+            // (envs/qrmsa.pyx:801-834), which need not give back what the heuristic meant (heuristics.py:36-54 encodes formats
+            // outside the window past the codec's range): do what the reference's loop does
+            if (P.n_mods_consider < P.n_mods && mode == kModePolicyStep && ch.route >= 0)
+                outcome = evaluate_action<UA, R32>(c, src, dst, lp, mg, ch.action, ch);
         }
         if (mode == kModePolicyOnly) {
             if (c.lane == 0) { act_out[c.replica] = ch.action; if (flag_out) flag_out[c.replica] = (uint8_t)ch.flags; }
@@ -129,8 +134,8 @@ __global__ __launch_bounds__(64) void k_observe(const Params *__restrict__ Pp, f
     ctx_bind(c, smem);
     load_state(c);
     double *Fx = reinterpret_cast<double *>(smem + lds_bytes(P));
-    const size_t obs_dim = 3 + P.k_paths + (size_t)P.k_paths * P.n_mods * 12;
-    const size_t nact = (size_t)P.k_paths * P.n_mods * P.n_slots + 1;
+    const size_t obs_dim = 3 + P.k_paths + (size_t)P.k_paths * P.n_mods_consider * 12;
+    const size_t nact = (size_t)P.k_paths * P.n_mods_consider * P.n_slots + 1;
     // extra LDS of the observation kernel: Fx f64[2S+2] | Vw u64[8*16] | xlist u16[2S+2] | needx u8[2S+2]
     uint64_t *Vw = reinterpret_cast<uint64_t *>(Fx + 2 * P.n_slots + 2);
     uint16_t *xlist = reinterpret_cast<uint16_t *>(Vw + kMaxMods * kMaxRowWords);
@@ -160,6 +165,7 @@ __global__ void k_reset_counters(Params P, const uint8_t *mask) {
     s.episode_disrupted_services = 0; s.rejected = 0;
     s.episode_defrag_cycles = 0; s.episode_service_reallocations = 0;
     for (int m = 0; m < 8; m++) s.episode_modulation_hist[m] = 0;
+    s.max_modulation_idx = P.n_mods - 1;                          // :437
     float *rr = P.svc_r + (size_t)r * P.capacity;
     for (int i = 0; i < s.active; i++) rr[i] = copysignf(INFINITY, rr[i]);
 }
@@ -388,6 +394,7 @@ static int build(ongym_env *env, const ongym_config *c) {
             return fail_arg(env, "link span parameters must be positive");
 
     P.n_nodes = N; P.n_links = E; P.n_paths = NP; P.k_paths = K; P.max_hops = H; P.n_mods = M; P.n_slots = c->n_slots;
+    P.n_mods_consider = (c->n_mods_consider <= 0 || c->n_mods_consider > M) ? M : c->n_mods_consider;   // qrmsa.pyx:313
     P.row_words = (c->n_slots + 63) / 64;
     P.ext_words = c->n_slots / 64 + 1;
     P.batch = c->batch; P.capacity = c->capacity; P.episode_length = c->episode_length; P.auto_reset = c->auto_reset;
@@ -552,6 +559,7 @@ static int build(ongym_env *env, const ongym_config *c) {
     // ---- lean first-fit kernel (ongym_fast.hpp): eligibility and its two extra tables ----
     {
         bool ok = uniform && P.ase_shortcut && !P.track_ids && !P.measure_disruptions && c->bit_rate_mode == 0 &&
+                  P.n_mods_consider == M &&
                   c->n_bit_rates <= 8 && E <= 52 && N <= 64 && P.tab_stride < kTabPitch && !host_tab.empty();
         const char *force = std::getenv("ONGYM_FORCE_GENERIC");
         if (force && force[0] == '1') ok = false;
@@ -959,6 +967,8 @@ int ongym_step_policy(ongym_env *env, int32_t policy, int32_t nsteps, ongym_step
     if (policy < ONGYM_POLICY_FIRST_FIT || policy >= ONGYM_POLICY_COUNT) return fail_arg(env, "unknown policy id");
     if (policy >= ONGYM_POLICY_LOWEST_SPECTRUM && env->P.k_paths > 8)
         return fail_arg(env, "this policy supports at most 8 candidate routes", ONGYM_E_LIMIT);
+    if (policy != ONGYM_POLICY_FIRST_FIT && env->P.n_mods_consider < env->P.n_mods)
+        return fail_arg(env, "only the first-fit policy is fused for modulations_to_consider < n_mods", ONGYM_E_LIMIT);
     if (nsteps <= 0) return fail_arg(env, "nsteps must be positive");
     if (!env->has_source) { env->err = "no request source: call ongym_seed or ongym_set_requests first"; return ONGYM_E_STATE; }
     HIP_TRY(env, hipSetDevice(env->cfg.device));
@@ -997,8 +1007,8 @@ int ongym_observe(ongym_env *env, float *obs, uint8_t *mask) {
     if (!P.uniform_alpha) return fail_arg(env, "observation kernel needs uniform attenuation", ONGYM_E_LIMIT);
     if (std::fabs(P.slot_bw - P.channel_width * 1e9) > 1e-6 * P.slot_bw) return fail_arg(env, "observation needs slot_bandwidth == channel_width*1e9");
     HIP_TRY(env, hipSetDevice(env->cfg.device));
-    const size_t obs_dim = 3 + P.k_paths + (size_t)P.k_paths * P.n_mods * 12;
-    const size_t nact = (size_t)P.k_paths * P.n_mods * P.n_slots + 1;
+    const size_t obs_dim = 3 + P.k_paths + (size_t)P.k_paths * P.n_mods_consider * 12;
+    const size_t nact = (size_t)P.k_paths * P.n_mods_consider * P.n_slots + 1;
     const size_t B = (size_t)P.batch;
     const size_t lds = field_lds(env);
     if (lds > 64 * 1024) {
@@ -1034,6 +1044,8 @@ int ongym_policy_actions(ongym_env *env, int32_t policy, int32_t *actions, uint8
     if (policy < ONGYM_POLICY_FIRST_FIT || policy >= ONGYM_POLICY_COUNT) return fail_arg(env, "unknown policy id");
     if (policy >= ONGYM_POLICY_LOWEST_SPECTRUM && env->P.k_paths > 8)
         return fail_arg(env, "this policy supports at most 8 candidate routes", ONGYM_E_LIMIT);
+    if (policy != ONGYM_POLICY_FIRST_FIT && env->P.n_mods_consider < env->P.n_mods)
+        return fail_arg(env, "only the first-fit policy is fused for modulations_to_consider < n_mods", ONGYM_E_LIMIT);
     HIP_TRY(env, hipSetDevice(env->cfg.device));
     int rc;
     if (env->cfg.io_device) return launch_run(env, kModePolicyOnly, policy, 1, nullptr, actions, flags, nullptr);

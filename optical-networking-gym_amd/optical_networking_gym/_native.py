@@ -45,7 +45,7 @@ class OngymConfig(C.Structure):
         ("node_cum", _f64p),
         ("replica_launch_power_w", _f64p), ("replica_load", _f64p), ("replica_margin", _f64p),
         ("path_len_norm", _f64p), ("max_bit_rate", C.c_double),
-        ("track_service_ids", C.c_int32), ("reserved_", C.c_int32),
+        ("track_service_ids", C.c_int32), ("n_mods_consider", C.c_int32),
     ]
 
 
@@ -72,6 +72,7 @@ STATS_DTYPE = np.dtype([
     ("total_steps", "<i8"), ("total_accepted", "<i8"), ("total_gn_evals", "<i8"),
     ("total_interferer_terms", "<i8"), ("total_paths_tried", "<i8"), ("total_path_hops", "<i8"),
     ("total_gn_shortcuts", "<i8"), ("total_active_sum", "<i8"), ("current_time", "<f8"), ("active", "<i4"), ("flags", "<i4"),
+    ("max_modulation_idx", "<i4"), ("reserved0_", "<i4"),
     # terminal-step snapshot (kept last, see include/ongym.h)
     ("last_episode_processed", "<i8"), ("last_episode_accepted", "<i8"), ("last_rejected", "<i8"),
     ("last_service_blocking_rate", "<f8"), ("last_episode_service_blocking_rate", "<f8"),
@@ -96,7 +97,8 @@ class ConfigHolder:
                  defragmentation: bool = False, n_defrag_services: int = 0,
                  replica_launch_power_dbm: Optional[Sequence[float]] = None,
                  replica_load: Optional[Sequence[float]] = None,
-                 replica_margin: Optional[Sequence[float]] = None, track_service_ids: bool = False):
+                 replica_margin: Optional[Sequence[float]] = None, track_service_ids: bool = False,
+                 modulations_to_consider: Optional[int] = None):
         if capacity % 64 or capacity <= 0:
             raise ValueError("capacity must be a positive multiple of 64")
         if load <= 0 or mean_service_holding_time <= 0:
@@ -136,6 +138,10 @@ class ConfigHolder:
         c.measure_disruptions = int(bool(measure_disruptions))
         c.defragmentation, c.n_defrag_services = int(bool(defragmentation)), int(n_defrag_services)
         c.track_service_ids = int(bool(track_service_ids))
+        mtc = len(mod_se) if modulations_to_consider is None else min(int(modulations_to_consider), len(mod_se))   # qrmsa.pyx:313
+        if mtc < 1:
+            raise ValueError("modulations_to_consider must be >= 1")
+        c.n_mods_consider = mtc
         c.frequency_start, c.slot_bandwidth = float(frequency_start), float(frequency_slot_bandwidth)
         c.channel_width = float(channel_width)
         c.launch_power_w = 10 ** ((float(launch_power_dbm) - 30) / 10)  # qrmsa.pyx:288
@@ -171,7 +177,7 @@ class ConfigHolder:
     @property
     def reject_action(self) -> int:
         c = self.struct
-        return c.k_paths * c.n_mods * c.n_slots
+        return c.k_paths * c.n_mods_consider * c.n_slots
 
 
 _LIB = None

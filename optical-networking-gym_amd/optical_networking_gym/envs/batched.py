@@ -35,14 +35,11 @@ class BatchedQRMSAEnv:
             modulations = topology.graph.get("modulations") if topology is not None else None
         if not modulations:
             raise ValueError("no modulations: pass `modulations=` or build the topology with them")
-        mtc = kwargs.pop("modulations_to_consider", 6)
         modulations = list(modulations)
-        if mtc < len(modulations):
-            # the reference's action codec then addresses only the top `mtc` formats (qrmsa.pyx:801-834) while its heuristics
-            # still walk all of them and encode the others out of range (heuristics.py:36-54): no consistent behaviour to
-            # reproduce. Pass the formats you want considered instead.
-            raise NotImplementedError("modulations_to_consider < len(modulations) is not supported: build the topology "
-                                      "with the modulation formats to consider")
+        # modulations_to_consider < len(modulations) (qrmsa.pyx:313): the action space addresses a window of that many formats
+        # below max_modulation_idx (codec :801-834); observation() moves the window per request (:543-581, 712-717)
+        mtc = min(int(kwargs.pop("modulations_to_consider", len(modulations))), len(modulations))
+        kwargs["modulations_to_consider"] = mtc
         for dead in ("seed", "allow_rejection", "reset", "file_name", "blocks_to_consider", "gen_observation",
                      "bands", "bandwidth", "k_paths"):
             kwargs.pop(dead, None)
@@ -143,8 +140,8 @@ class BatchedQRMSAEnv:
     def observe(self):
         """observation() + action mask of every replica's current request: (float32 [B, obs_dim], uint8 [B, n_actions])."""
         c = self.holder.struct
-        obs = np.zeros((self.batch_size, 3 + c.k_paths + c.k_paths * c.n_mods * 12), np.float32)
-        mask = np.zeros((self.batch_size, c.k_paths * c.n_mods * c.n_slots + 1), np.uint8)
+        obs = np.zeros((self.batch_size, 3 + c.k_paths + c.k_paths * c.n_mods_consider * 12), np.float32)
+        mask = np.zeros((self.batch_size, c.k_paths * c.n_mods_consider * c.n_slots + 1), np.uint8)
         self._check(self.lib.ongym_observe(self._h, obs.ctypes.data, mask.ctypes.data), "ongym_observe")
         return obs, mask
 

@@ -96,9 +96,9 @@ class QRMSAEnv:
                  bands: object = None, device: int = 0, capacity: int = 1024, sync_views: bool = True,
                  requests: Optional[np.ndarray] = None):
         self.gen_observation = bool(gen_observation)
-        if gen_observation and (bit_rate_selection != "discrete" or modulations_to_consider < len(topology.graph.get("modulations", []))):
-            raise NotImplementedError("gen_observation=True needs discrete bit rates and modulations_to_consider == "
-                                      "len(modulations) (the reference's observation() reads max(bit_rates), qrmsa.pyx:679)")
+        if gen_observation and bit_rate_selection != "discrete":
+            raise NotImplementedError("gen_observation=True needs discrete bit rates (the reference's observation() reads "
+                                      "max(bit_rates), qrmsa.pyx:679)")
         self.defragmentation, self.n_defrag_services = bool(defragmentation), int(n_defrag_services)
         if bands and gen_observation:
             raise NotImplementedError("bands together with gen_observation=True is not built yet")
@@ -240,6 +240,8 @@ class QRMSAEnv:
     def _blank_observation(self):
         if self.gen_observation:   # observation() + action mask of the CURRENT request, computed on device (qrmsa.pyx:583-781)
             obs, mask = self._dev.observe()
+            # observation() moved the codec's format window (get_max_modulation_index, qrmsa.pyx:543-581, 680)
+            self.max_modulation_idx = int(self._dev.stats()[0]["max_modulation_idx"])
             return obs[0], {"mask": mask[0]}
         # gen_observation=False: zeros, including the reject slot of the mask (qrmsa.pyx:584-587)
         return (np.zeros(self.observation_space.shape, np.float32),

@@ -28,8 +28,8 @@ class QRMSAVecEnv:
         self.env = BatchedQRMSAEnv(topology, batch_size=num_envs, **kwargs)
         self.num_envs = int(num_envs)
         c = self.env.holder.struct
-        self.obs_dim = 3 + c.k_paths + c.k_paths * c.n_mods * 12
-        self.n_actions = c.k_paths * c.n_mods * c.n_slots + 1
+        self.obs_dim = 3 + c.k_paths + c.k_paths * c.n_mods_consider * 12
+        self.n_actions = c.k_paths * c.n_mods_consider * c.n_slots + 1
         self.env.seed(seed)
         self._mask = None
         self._obs = None

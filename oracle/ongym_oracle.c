@@ -477,19 +477,25 @@ void orc_gn_lists(orc_env *e, int path_id, int slot, int n, const int32_t *count
 }
 
 /* ---- action codec (heuristics/heuristics.py:36-54; envs/qrmsa.pyx:801-834) ------------------------------------- */
+/* modulations_to_consider = min(kwarg, len(modulations)) (envs/qrmsa.pyx:313) */
+static int mods_consider(const orc_env *e) {
+    int mc = e->cfg.n_mods_consider;
+    return (mc <= 0 || mc > e->cfg.n_mods) ? e->cfg.n_mods : mc;
+}
 int orc_encode_action(const orc_env *e, int path_index, int mod_index, int slot) {
     int rel = e->max_mod_idx - mod_index;
-    return path_index * e->cfg.n_mods * e->cfg.n_slots + rel * e->cfg.n_slots + slot;
+    return path_index * mods_consider(e) * e->cfg.n_slots + rel * e->cfg.n_slots + slot;
 }
 void orc_decode_action(const orc_env *e, int action, int out[3]) {
-    int M = e->cfg.n_mods, S = e->cfg.n_slots, K = e->cfg.k_paths;
+    int Mc = mods_consider(e), S = e->cfg.n_slots, K = e->cfg.k_paths;
     int slot = action % S; action /= S;
-    int r = action % M; action /= M;
+    int r = action % Mc; action /= Mc;
     int route = action % K;
-    int mod = (e->max_mod_idx > 1) ? e->max_mod_idx - r : (M - 1) - r;  /* :821-825 */
+    int mod = (e->max_mod_idx > 1) ? e->max_mod_idx - r : (Mc - 1) - r;  /* :821-825 */
     out[0] = route; out[1] = mod; out[2] = slot;
 }
-int orc_reject_action(const orc_env *e) { return e->cfg.k_paths * e->cfg.n_mods * e->cfg.n_slots; }
+int orc_reject_action(const orc_env *e) { return e->cfg.k_paths * mods_consider(e) * e->cfg.n_slots; }
+int orc_max_modulation_idx(const orc_env *e) { return e->max_mod_idx; }
 
 /* ---- heuristic_shortest_available_path_first_fit_best_modulation (heuristics/heuristics.py:923-966) ------------ */
 int orc_policy_first_fit(orc_env *e, int *blocked_resources, int *blocked_osnr) {
@@ -956,6 +962,7 @@ void orc_stats(const orc_env *e, ongym_stats *s) {
     s->total_interferer_terms = e->total_terms; s->total_paths_tried = e->total_paths;
     s->total_path_hops = e->total_hops; s->total_active_sum = e->total_active_sum;
     s->total_gn_shortcuts = 0; s->current_time = e->current_time; s->active = e->n_running;
+    s->max_modulation_idx = e->max_mod_idx;
     s->flags = e->flags;
 }
 
@@ -983,7 +990,7 @@ int orc_services(const orc_env *e, ongym_service *out) {
 /* ---- observation() + action mask (envs/qrmsa.pyx:583-781) and calculate_osnr_observation (core/osnr.pyx:259-369) ----
  * gen_observation=True path. obs: float32[1 + 2 + k + k*M*12], mask: uint8[k*M*S + 1].
  * path_len_norm[p] = (path length - min link length) / (max link length - min link length)  (:692-705, quirk Q10)
- * max_bit_rate = max(bit_rates) (:679). Assumes n_mods == modulations_to_consider (max_modulation_idx stays M-1, :543-581). */
+ * max_bit_rate = max(bit_rates) (:679). */
 static double osnr_observation(const orc_env *e, int path_id, double bw, double fc, double P, double gsnr_th) {
     const double beta_2 = -21.3e-27, gamma = 1.3e-3, h_plank = 6.626e-34, pi = M_PI;
     double acc_gsnr = 0.0;
@@ -1014,8 +1021,42 @@ static double osnr_observation(const orc_env *e, int path_id, double bw, double 
     return nearbyint(((gsnr - gsnr_th) / fabs(gsnr_th)) * 1e10) / 1e10;   /* np.round(x, 10), core/osnr.pyx:368 */
 }
 
+/* get_max_modulation_index (envs/qrmsa.pyx:543-581): path-major, best modulation first, candidates ascending; the first
+ * candidate whose calculate_osnr reaches minimum_osnr + margin fixes max_modulation_idx = max(its modulation index,
+ * modulations_to_consider - 1); none: modulations_to_consider - 1. */
+void orc_get_max_modulation_index(orc_env *e) {
+    int S = e->cfg.n_slots, K = e->cfg.k_paths, M = e->cfg.n_mods, N = e->cfg.n_nodes, Mc = mods_consider(e);
+    int32_t *avail = e->scratch_avail;
+    int32_t *starts = (int32_t *)malloc(sizeof(int32_t) * (S + 1));
+    for (int k = 0; k < K; k++) {
+        int p = e->pair_paths[(e->cur.src * N + e->cur.dst) * K + k];
+        if (p < 0) break;
+        orc_available(e, p, avail);
+        for (int m = M - 1; m >= 0; m--) {
+            int n = orc_number_slots(e, e->cur.bit_rate, m);
+            int cnt = orc_candidates(avail, S, n, starts, S + 1);
+            for (int i = 0; i < cnt; i++) {
+                double o[3];
+                gn_state(e, p, starts[i], n, o, 0);
+                if (o[0] >= e->mod_thr[m] + e->margin) {
+                    e->max_mod_idx = m > Mc - 1 ? m : Mc - 1;
+                    free(starts);
+                    return;
+                }
+            }
+        }
+    }
+    e->max_mod_idx = Mc - 1;
+    free(starts);
+}
+
 void orc_observe(orc_env *e, const double *path_len_norm, double max_bit_rate, float *obs, uint8_t *mask) {
-    int S = e->cfg.n_slots, K = e->cfg.k_paths, M = e->cfg.n_mods, N = e->cfg.n_nodes;
+    int S = e->cfg.n_slots, K = e->cfg.k_paths, Mall = e->cfg.n_mods, N = e->cfg.n_nodes;
+    const int M = mods_consider(e);                                     /* num_mod_to_consider */
+    orc_get_max_modulation_index(e);                                    /* :680 */
+    /* the window of formats the observation describes (:712-717) */
+    const int start_index = e->max_mod_idx <= 1 ? 0 : (e->max_mod_idx - (M - 1) > 0 ? e->max_mod_idx - (M - 1) : 0);
+    (void)Mall;
     int32_t *avail = e->scratch_avail;
     int32_t *starts = (int32_t *)malloc(sizeof(int32_t) * (S + 1));
     double *vals = (double *)malloc(sizeof(double) * (S + 1));
@@ -1035,7 +1076,7 @@ void orc_observe(orc_env *e, const double *path_len_norm, double max_bit_rate, f
             float *f = &obs[o]; o += 12;
             for (int j = 0; j < 12; j++) f[j] = -1.0f;
             if (p < 0) continue;
-            int m = M - 1 - mi;                                          /* mod_list = reversed(modulations[0:M]) :716-717 */
+            int m = start_index + M - 1 - mi;                            /* mod_list = reversed(modulations[start:start+M]) :716-717 */
             int n = orc_number_slots(e, e->cur.bit_rate, m);
             orc_available(e, p, avail);
             int cnt = orc_candidates(avail, S, n, starts, S + 1);

@@ -406,7 +406,7 @@ def export_kats():
 
 
 def run_observation(tag, topo_name, seed, load, S, steps, bit_rates=(10, 40, 100, 400), launch_power_dbm=0.0,
-                    margin=0.0, k=5):
+                    margin=0.0, k=5, modulations_to_consider=6):
     """gen_observation=True: observation vector (qrmsa.pyx:583-781) and action mask at every step of a first-fit run."""
     topo = load_topology(topo_name, k)
     random.Random = seeded_random(seed)
@@ -416,30 +416,46 @@ def run_observation(tag, topo_name, seed, load, S, steps, bit_rates=(10, 40, 100
             num_spectrum_resources=S, launch_power_dbm=launch_power_dbm, bandwidth=S * 12.5e9,
             frequency_start=3e8 / 1565e-9, frequency_slot_bandwidth=12.5e9, bit_rate_selection="discrete",
             bit_rates=bit_rates, margin=margin, file_name="", measure_disruptions=False, k_paths=k,
-            modulations_to_consider=6, defragmentation=False, n_defrag_services=0, gen_observation=True)
+            modulations_to_consider=modulations_to_consider, defragmentation=False, n_defrag_services=0,
+            gen_observation=True)
     finally:
         random.Random = _OrigRandom
     reqs = [request_tuple(env)]
     obs0, info0 = env.reset()
     reqs.append(request_tuple(env))
     obs_l, mask_l, act_l = [obs0], [np.packbits(info0["mask"], bitorder="little")], []
+    maxidx_l, dec_l, acc_l = [int(env.env.max_modulation_idx)], [], []
+    mask = info0["mask"]
     for i in range(steps):
-        action, _, _ = H.heuristic_shortest_available_path_first_fit_best_modulation(env)
+        if modulations_to_consider == 6:
+            action, _, _ = H.heuristic_shortest_available_path_first_fit_best_modulation(env)
+        else:
+            # the heuristics encode out-of-window formats past the codec's range (heuristics.py:36-54): act on the MASK like
+            # the RL agents of examples/ONDM_2025 do — lowest valid action, every 9th step the highest valid non-reject one
+            valid = np.flatnonzero(mask[:-1])
+            action = int(valid[0] if i % 9 else valid[-1]) if len(valid) else len(mask) - 1
+        dec_l.append([-1, -1, -1] if action == len(mask) - 1 else [int(v) for v in env.env.encoded_decimal_to_array(int(action))])
         obs, reward, done, _, info = env.step(int(action))
+        mask = info["mask"]
         act_l.append(int(action))
+        acc_l.append(int(env.env.topology.graph["services"][-1].accepted))
         obs_l.append(obs); mask_l.append(np.packbits(info["mask"], bitorder="little"))
+        maxidx_l.append(int(env.env.max_modulation_idx))
         reqs.append(request_tuple(env))
-        assert env.env.max_modulation_idx == 5
+        assert modulations_to_consider < 6 or env.env.max_modulation_idx == 5
     reqs_a = np.array(reqs, dtype=np.float64)
     np.savez_compressed(os.path.join(HERE, f"{tag}.npz"),
                         req_at=reqs_a[:, 0].astype(np.float32), req_ht=reqs_a[:, 1].astype(np.float32),
                         req_src=reqs_a[:, 2].astype(np.int32), req_dst=reqs_a[:, 3].astype(np.int32),
                         req_br=reqs_a[:, 4].astype(np.float32), action=np.array(act_l, np.int32),
-                        obs=np.stack(obs_l).astype(np.float32), mask=np.stack(mask_l))
+                        obs=np.stack(obs_l).astype(np.float32), mask=np.stack(mask_l),
+                        max_modulation_idx=np.array(maxidx_l, np.int32), decoded=np.array(dec_l, np.int32),
+                        accepted=np.array(acc_l, np.uint8))
     json.dump(dict(tag=tag, topology=topo_name, seed=seed, load=load, S=S, steps=steps, bit_rates=list(bit_rates),
                    launch_power_dbm=launch_power_dbm, margin=margin, k_paths=k, episode_length=steps + 50,
                    bit_rate_selection="discrete", frequency_start=3e8 / 1565e-9, slot_bw=12.5e9,
-                   mean_holding=10800.0, initial_resets=2, n_actions=int(env.env.action_space.n)),
+                   mean_holding=10800.0, initial_resets=2, n_actions=int(env.env.action_space.n),
+                   modulations_to_consider=modulations_to_consider),
               open(os.path.join(HERE, f"{tag}.json"), "w"), indent=1)
     print(f"{tag}: {steps} steps, obs dim {obs_l[0].shape[0]}, mask ones first/last {int(info0['mask'].sum())}/{int(info['mask'].sum())}")
 
@@ -448,6 +464,9 @@ OBS = {
     "obs_nsfnet320": dict(topo_name="nsfnet", seed=31, load=300, S=320, steps=120),
     "obs_nsfnet320_dense": dict(topo_name="nsfnet", seed=32, load=2500, S=320, steps=160, margin=0.5,
                                 launch_power_dbm=-1.0),
+    # modulations_to_consider < len(modulations): sliding window below max_modulation_idx (qrmsa.pyx:543-581, 712-717, 801-834)
+    "obs_nsfnet320_mtc4": dict(topo_name="nsfnet", seed=33, load=1500, S=320, steps=140, modulations_to_consider=4),
+    "obs_nsfnet160_mtc2": dict(topo_name="nsfnet", seed=34, load=900, S=160, steps=120, modulations_to_consider=2),
 }
 
 # ----------------------------------------------------------------------------------------------------------------

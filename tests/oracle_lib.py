@@ -59,6 +59,7 @@ def lib():
         L.orc_request.argtypes = [vp, vp]
         L.orc_services.argtypes = [vp, vp]
         L.orc_observe.argtypes = [vp, vp, C.c_double, vp, vp]
+        L.orc_max_modulation_idx.argtypes = [vp]
         L.orc_run_first_fit.argtypes = [vp, C.c_int, vp]
         L.orc_batch_run_first_fit.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         L.orc_batch_run_first_fit.restype = C.c_int64
@@ -182,11 +183,15 @@ class OracleEnv:
 
     def observe(self, path_len_norm: np.ndarray, max_bit_rate: float):
         c = self.cfg
-        obs = np.zeros(1 + 2 + c.k_paths + c.k_paths * c.n_mods * 12, np.float32)
-        mask = np.zeros(c.k_paths * c.n_mods * c.n_slots + 1, np.uint8)
+        obs = np.zeros(1 + 2 + c.k_paths + c.k_paths * c.n_mods_consider * 12, np.float32)
+        mask = np.zeros(c.k_paths * c.n_mods_consider * c.n_slots + 1, np.uint8)
         pl = np.ascontiguousarray(path_len_norm, np.float64)
         self.L.orc_observe(self.h, pl.ctypes.data, float(max_bit_rate), obs.ctypes.data, mask.ctypes.data)
         return obs, mask
+
+    @property
+    def max_modulation_idx(self) -> int:
+        return self.L.orc_max_modulation_idx(self.h)
 
     def services(self) -> np.ndarray:
         out = np.zeros(self.cfg.capacity, SERVICE_DTYPE)

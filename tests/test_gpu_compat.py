@@ -148,8 +148,9 @@ def test_unbuilt_features_fail_loudly():
     topology = get_topology(bundled_topology_path("nsfnet_chen.txt"), None, jocn_modulations(), 80, 0.2, 4.5, 5)
     with pytest.raises(NotImplementedError):
         QRMSAEnvWrapper(topology=topology, load=300, gen_observation=True)
-    with pytest.raises(NotImplementedError, match="modulations_to_consider"):
-        QRMSAEnvWrapper(topology=topology, load=300, gen_observation=False, modulations_to_consider=3)
+    narrow = QRMSAEnvWrapper(topology=topology, load=300, gen_observation=False, modulations_to_consider=3)
+    assert narrow.env.action_space.n == 5 * 3 * 320 + 1 and narrow.env.reject_action == 5 * 3 * 320   # qrmsa.pyx:313, 319-321
+    assert narrow.env.encoded_decimal_to_array(1 * 3 * 320 + 2 * 320 + 7) == [1, 3, 7]                # window 5, 4, 3
     import networkx as nx
     with pytest.raises(KeyError, match="ksp"):
         QRMSAEnvWrapper(topology=nx.Graph(), gen_observation=False)

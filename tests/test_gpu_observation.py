@@ -30,6 +30,75 @@ def test_observation_and_mask_vs_reference(tag):
             assert not rec["retry"] and not (rec["flags"] & nat.F_QOT_ERROR)
 
 
+@pytest.mark.parametrize("tag", ["obs_nsfnet320_mtc4", "obs_nsfnet160_mtc2"])
+def test_modulations_to_consider_window_vs_reference(tag):
+    """modulations_to_consider < len(modulations) (qrmsa.pyx:313): ongym_observe moves max_modulation_idx like
+    get_max_modulation_index (:543-581) and reports the window below it (:712-717); ongym_step_actions decodes with the
+    window codec (:801-834).  Reference run driven by its own mask, every step compared."""
+    meta, d = load_traj(tag)
+    Mc = meta["modulations_to_consider"]
+    env = make_env(meta, auto_reset=False, modulations_to_consider=Mc)
+    assert env.num_actions == meta["n_actions"] == 5 * Mc * meta["S"] + 1
+    env.set_requests(traj_requests(d))
+    for _ in range(meta["initial_resets"]):
+        env.reset()
+    for i in range(meta["steps"] + 1):
+        obs, mask = env.observe()
+        assert env.stats()[0]["max_modulation_idx"] == d["max_modulation_idx"][i], i
+        want_mask = np.unpackbits(d["mask"][i], bitorder="little")[:meta["n_actions"]]
+        np.testing.assert_array_equal(mask[0], want_mask, err_msg=f"mask step {i}")
+        np.testing.assert_allclose(obs[0], d["obs"][i], rtol=2e-6, atol=2e-7, err_msg=f"obs step {i}")
+        if i < meta["steps"]:
+            rec = env.step(np.array([d["action"][i]], np.int32))[0]
+            assert not rec["retry"] and not (rec["flags"] & nat.F_QOT_ERROR)
+            assert rec["accepted"] == d["accepted"][i]
+            if rec["accepted"]:
+                assert [rec["route"], rec["modulation"], rec["slot"]] == d["decoded"][i].tolist(), i
+
+
+def test_modulations_to_consider_vs_oracle_mask_driven():
+    """The window on evolving states: 10 replicas with different launch powers, each step observe -> lowest valid action of
+    the mask (every 7th step the highest) -> step, device vs oracle in lockstep; then the fused first-fit heuristic's action
+    index under a narrow codec equals the oracle's (heuristics.py:36-54: relative to max_modulation_idx, window-wide radix)."""
+    B, Mc, S, steps = 10, 3, 192, 160
+    lps = np.linspace(-6.0, 2.0, B)
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=S, capacity=1024, load=700, bit_rate_selection="discrete",
+              bit_rates=(10, 40, 100, 400), auto_reset=True, modulations_to_consider=Mc, replica_launch_power_dbm=lps)
+    holder = nat.ConfigHolder(golden_tables("nsfnet"), batch=B, **kw)
+    env = BatchedQRMSAEnv(tables=golden_tables("nsfnet"), batch_size=B, **kw)
+    env.seed(9); env.reset()
+    pl = np.ctypeslib.as_array(holder.struct.path_len_norm, shape=(holder.struct.n_paths,))
+    oracles = []
+    for r in range(B):
+        o = OracleEnv(holder, replica=r); o.seed(9); o.reset()
+        oracles.append(o)
+    seen = set()
+    for t in range(steps):
+        obs, mask = env.observe()
+        st = env.stats()
+        acts = np.zeros(B, np.int32)
+        for r, o in enumerate(oracles):
+            want_obs, want_mask = o.observe(pl, holder.struct.max_bit_rate)
+            assert st[r]["max_modulation_idx"] == o.max_modulation_idx, (t, r)
+            seen.add(o.max_modulation_idx)
+            np.testing.assert_array_equal(mask[r], want_mask, err_msg=f"mask step {t} replica {r}")
+            np.testing.assert_allclose(obs[r], want_obs, rtol=2e-6, atol=2e-7, err_msg=f"obs step {t} replica {r}")
+            valid = np.flatnonzero(want_mask[:-1])
+            acts[r] = (valid[-1] if t % 7 == 6 else valid[0]) if len(valid) else env.reject_action
+        rec = env.step(acts)
+        for r, o in enumerate(oracles):
+            rc, w = o.step(int(acts[r]))
+            assert rc == 0
+            for f in ("accepted", "route", "modulation", "slot", "nslots", "active", "retry"):
+                assert rec[r][f] == w[f], (t, r, f)
+    assert len(seen) >= 3 and obs.shape == (B, 3 + 5 + 5 * Mc * 12) and mask.shape == (B, 5 * Mc * S + 1)
+    a_dev, _ = env.policy_actions()
+    for r, o in enumerate(oracles):
+        assert a_dev[r] == o.policy_first_fit()[0], r
+    with pytest.raises(Exception):
+        env.step_policy(1, policy=nat.POLICY_LOAD_BALANCING)      # only first fit is fused for a narrow codec
+
+
 @pytest.mark.parametrize("topo,S,load", [("nsfnet", 320, 500), ("nobel-eu", 320, 700), ("cost239", 192, 300)])
 def test_observation_vs_oracle_random_states(topo, S, load):
     B = 12

@@ -151,7 +151,7 @@ OBS_TAGS = ["obs_nsfnet320", "obs_nsfnet320_dense"]
 
 def obs_setup(tag):
     meta, d = load_traj(tag)
-    h = holder_for(meta, capacity=1024)
+    h = holder_for(meta, capacity=1024, modulations_to_consider=meta.get("modulations_to_consider", 6))
     reqs = traj_requests(d)
     return meta, d, h, reqs
 
@@ -175,6 +175,33 @@ def test_observation_and_mask_vs_reference(tag):
         if i < meta["steps"]:
             rc, _ = env.step(int(d["action"][i]))
             assert rc == 0
+
+
+@pytest.mark.parametrize("tag", ["obs_nsfnet320_mtc4", "obs_nsfnet160_mtc2"])
+def test_modulations_to_consider_window_vs_reference(tag):
+    """modulations_to_consider < len(modulations): observation() first moves max_modulation_idx
+    (get_max_modulation_index, qrmsa.pyx:543-581), describes the window of formats below it (:712-717) and the action codec
+    addresses that window (:801-834).  Reference run driven by its own mask (lowest / highest valid action)."""
+    meta, d, h, reqs = obs_setup(tag)
+    Mc = meta["modulations_to_consider"]
+    assert h.struct.n_mods_consider == Mc and h.reject_action == 5 * Mc * meta["S"] == meta["n_actions"] - 1
+    env = OracleEnv(h)
+    env.set_trace(reqs)
+    for _ in range(meta["initial_resets"]):
+        env.reset()
+    pl = np.ctypeslib.as_array(h.struct.path_len_norm, shape=(h.struct.n_paths,))
+    assert len(set(d["max_modulation_idx"].tolist())) >= 3          # the window really moves
+    for i in range(meta["steps"] + 1):
+        obs, mask = env.observe(pl, h.struct.max_bit_rate)          # the reference calls observation() in reset() and step()
+        assert env.max_modulation_idx == d["max_modulation_idx"][i], i
+        np.testing.assert_array_equal(mask, np.unpackbits(d["mask"][i], bitorder="little")[:meta["n_actions"]], err_msg=f"mask step {i}")
+        np.testing.assert_allclose(obs, d["obs"][i], rtol=2e-6, atol=2e-7, err_msg=f"obs step {i}")
+        if i < meta["steps"]:
+            a = int(d["action"][i])
+            if a != h.reject_action:
+                assert env.decode(a) == d["decoded"][i].tolist(), i
+            rc, r = env.step(a)
+            assert rc == 0 and r["accepted"] == d["accepted"][i], i
 
 
 # ---- load_balancing_best_modulation (heuristics.py:547-627) -----------------------------------------------------------

@@ -33,7 +33,7 @@ env = BatchedQRMSAEnv(tables=bench.build_tables(wl["topology"]), modulations=ben
                       num_spectrum_resources=wl["S"], capacity=wl["capacity"], episode_length=1000, auto_reset=True,
                       load=wl["load"], bit_rate_selection="discrete", bit_rates=wl["bit_rates"], io_device=True)
 c = env.holder.struct
-obs_dim, nact = 3 + c.k_paths + c.k_paths * c.n_mods * 12, c.k_paths * c.n_mods * c.n_slots + 1
+obs_dim, nact = 3 + c.k_paths + c.k_paths * c.n_mods_consider * 12, c.k_paths * c.n_mods_consider * c.n_slots + 1
 dev = torch.device("cuda", 0)
 obs = torch.empty((B, obs_dim), dtype=torch.float32, device=dev)
 mask = torch.empty((B, nact), dtype=torch.uint8, device=dev)

@@ -9,7 +9,8 @@ import numpy as np  # noqa: E402
 import bench  # noqa: E402
 from optical_networking_gym.envs.batched import BatchedQRMSAEnv  # noqa: E402
 
-for B in (4096, 16384):
+batches = [int(a) for a in sys.argv[1:]] or [4096, 16384]
+for B in batches:
     wl = bench.WORKLOADS["nsfnet320"]
     env = BatchedQRMSAEnv(tables=bench.build_tables(wl["topology"]), modulations=bench.jocn_modulations(), batch_size=B,
                           num_spectrum_resources=wl["S"], capacity=wl["capacity"], episode_length=1000, auto_reset=True,
