@@ -150,6 +150,11 @@ __host__ __device__ inline size_t lds_bytes(const Params &P) {
 #define STAMPW(c, idx) do { } while (0)
 #endif
 
+// k_observe: can the valid-start words and the need flags live where the state block keeps the release times?
+__host__ __device__ inline bool obs_alias_sr(const Params &P) {
+    return (size_t)P.capacity * 4 >= (size_t)kMaxMods * kMaxRowWords * 8 + (size_t)2 * P.n_slots + 2 + 8;
+}
+
 // extra LDS of the kernels that evaluate EVERY candidate of a path (observation, highest-SNR policy)
 struct FieldLds { double *Fx; uint64_t *Vw; uint16_t *xlist; uint8_t *needx; };
 
@@ -1467,34 +1472,92 @@ __device__ __forceinline__ void apply_step(Ctx &c, const Choice &ch, int outcome
 // a superposition of per-interferer profiles that does not depend on the candidate's own width: F is built ONCE per
 // path over all 2S+1 centres (lanes over x -> the pair-table reads of one interferer are contiguous), then each of the
 // M x (valid starts) candidates costs one LDS read + the O(1) ASE/self terms + one log10.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+// Wave-wide reductions without the LDS crossbar: symmetric DPP exchanges inside each row of 16 lanes (as wave_sum), then
+// the four row results through v_readlane; the result is wave-uniform.
 __device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    return v;
+    v += dpp_i32<0xB1>(v); v += dpp_i32<0x4E>(v); v += dpp_i32<0x141>(v); v += dpp_i32<0x140>(v);
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
+           (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
 __device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m));
-    return v;
+    v = max(v, dpp_i32<0xB1>(v)); v = max(v, dpp_i32<0x4E>(v)); v = max(v, dpp_i32<0x141>(v)); v = max(v, dpp_i32<0x140>(v));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 __device__ __forceinline__ double wave_max_f64(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
-    return v;
+    v = fmax(v, dpp_f64<0xB1>(v)); v = fmax(v, dpp_f64<0x4E>(v)); v = fmax(v, dpp_f64<0x141>(v)); v = fmax(v, dpp_f64<0x140>(v));
+    return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 
 
-// Field builder shared by the observation kernel and the highest-SNR policy. For path `p` (free bitmap `free_ext`):
-//   Vw[mi*16 + w] : valid starts of modulation mi (best first) as run-AND words
-//   Fx[x]         : interferer part of the NLI sum for a candidate centred at half-slot x, at every x = 2s + n that some
-//                   valid (modulation, start) pair produces (0 elsewhere)
+// One tile of <= 64 interferers (lane t holds interferer t: centre c2k, slots nk, summed link weights w1, Phi-weighted
+// pw2) added to the field at up to NA x 64 needed centres whose partial sums stay in registers: the interferer's
+// parameters are broadcast ONCE (6 v_readlane), then each 64-centre chunk costs |x - c|, one address op, one 16-byte
+// gather from the pitch-2048 pair table and two FMAs.  No validity test is needed: a needed centre x = 2s + n comes from
+// a VALID start, whose slots do not overlap any running service on a shared link, so |x - c_k| > n_k always; lanes
+// beyond the list hold x = 0 and are not stored.
+template <int NA>
+__device__ __forceinline__ void field_tile(const Params &P, int lane, double *Fx, const uint16_t *xlist, int nxl, int g0,
+                                           int c2k, int nk, double w1, double pw2, int tile_n) {
+    const char __attribute__((address_space(1))) *tab = (const char __attribute__((address_space(1))) *)P.pair_tab2k;
+    uint32_t xs[NA];
+    double f[NA];
+#pragma unroll
+    for (int a = 0; a < NA; a++) {
+        const int i = g0 + a * kWave + lane;
+        xs[a] = i < nxl ? xlist[i] : 0;
+        f[a] = 0.0;
+    }
+    // TU interferers per round: TU x NA independent gathers are in flight before the first FMA needs one (the loop is bound by
+    // the L2 round trip otherwise); a round past the end of the tile repeats the last interferer with zero weights
+#ifndef ONGYM_OBS_TU
+#define ONGYM_OBS_TU 2
+#endif
+    constexpr int TU = NA <= 4 ? 2 * ONGYM_OBS_TU : ONGYM_OBS_TU;
+    for (int t = 0; t < tile_n; t += TU) {
+        uint32_t cc[TU], key4[TU];
+        double w1t[TU], pw2t[TU];
+#pragma unroll
+        for (int u = 0; u < TU; u++) {
+            const int tt = min(t + u, tile_n - 1);
+            const bool real = t + u < tile_n;
+            cc[u] = (uint32_t)__builtin_amdgcn_readlane(c2k, tt);
+            key4[u] = (uint32_t)(__builtin_amdgcn_readlane(nk, tt) - 1) << 15;      // row * 2048 entries * 16 bytes
+            w1t[u] = real ? readlane_f64(w1, tt) : 0.0;
+            pw2t[u] = real ? readlane_f64(pw2, tt) : 0.0;
+        }
+        double qa[TU][NA], qr[TU][NA];
+#pragma unroll
+        for (int u = 0; u < TU; u++)
+#pragma unroll
+            for (int a = 0; a < NA; a++) {
+                const uint32_t adi = __builtin_amdgcn_sad_u16(xs[a], cc[u], 0);
+                const double __attribute__((address_space(1))) *q =
+                    (const double __attribute__((address_space(1))) *)(tab + (size_t)(key4[u] | (adi << 4)));
+                qa[u][a] = q[0]; qr[u][a] = q[1];
+            }
+#pragma unroll
+        for (int u = 0; u < TU; u++)
+#pragma unroll
+            for (int a = 0; a < NA; a++) f[a] += qa[u][a] * w1t[u] - qr[u][a] * pw2t[u];
+    }
+#pragma unroll
+    for (int a = 0; a < NA; a++) {
+        const int i = g0 + a * kWave + lane;
+        if (i < nxl) Fx[xs[a]] += f[a];
+    }
+}
 
 template <bool R32>
 __device__ __forceinline__ void build_field(Ctx &c, const PathRef &p, uint64_t free_ext, const FieldLds &fl) {
     const Params &P = c.P;
     const int M = P.n_mods, S = P.n_slots, nx = 2 * S + 1, W = P.row_words;
     double *Fx = fl.Fx; uint64_t *Vw = fl.Vw; uint16_t *xlist = fl.xlist; uint8_t *needx = fl.needx;
+    STAMPW(c, 1);
     const int L = gn_build_list<R32>(c, p.m0, p.m1);
+    STAMPW(c, 2);
     // valid starts of every modulation (run-AND words, lane w = word w) and the candidate centres x = 2s + n they
     // produce: the field is only needed there (a loaded network has few valid starts)
     for (int x = c.lane; x < nx + 1; x += kWave) { Fx[x] = 0.0; needx[x] = 0; }
@@ -1513,15 +1576,19 @@ __device__ __forceinline__ void build_field(Ctx &c, const PathRef &p, uint64_t f
         }
     }
     wave_sync();
+    STAMPW(c, 3);
     for (int mi = 0; mi < M; mi++) {
         const int n = uniform_i32(c.nreq[M - 1 - mi]);
+        const uint64_t vrow = Vw[mi * kMaxRowWords + min(c.lane, kMaxRowWords - 1)];        // lane i = word i
         for (int i = 0; i < W; i++) {
-            const uint64_t w = Vw[mi * kMaxRowWords + i];
+            const uint64_t w = readlane_u64(vrow, i);
+            if (!w) continue;
             const int sl = i * 64 + c.lane;
             if (((w >> c.lane) & 1ull) && sl < S) needx[2 * sl + n] = 1;
         }
     }
     wave_sync();
+    STAMPW(c, 4);
     int nxl = 0;
     for (int x0 = 0; x0 < nx; x0 += kWave) {
         const int x = x0 + c.lane;
@@ -1531,6 +1598,7 @@ __device__ __forceinline__ void build_field(Ctx &c, const PathRef &p, uint64_t f
         nxl += __popcll((unsigned long long)bal);
     }
     wave_sync();
+    STAMPW(c, 5);
     for (int base = 0; base < L; base += kWave) {
         const int j = base + c.lane;
         int c2k = 0, nk = 0;
@@ -1554,6 +1622,16 @@ __device__ __forceinline__ void build_field(Ctx &c, const PathRef &p, uint64_t f
         // beyond the configured ones) -> branch-free inner loop with 4 gathers in flight
         const bool all_tab = __ballot(j < L && nk > P.tab_nmax) == 0;
         const auto *tab = G(reinterpret_cast<const double *>(P.pair_tab));
+        STAMPW(c, 6);
+        if (all_tab && P.pair_tab2k) {      // the fast form: partial sums of up to 8 chunks of centres in registers
+            for (int g0 = 0; g0 < nxl; g0 += 8 * kWave) {
+                const int chunks = (nxl - g0 + kWave - 1) / kWave;
+                if (chunks <= 4) field_tile<4>(P, c.lane, Fx, xlist, nxl, g0, c2k, nk, w1, pw2, tile_n);
+                else field_tile<8>(P, c.lane, Fx, xlist, nxl, g0, c2k, nk, w1, pw2, tile_n);
+            }
+            STAMPW(c, 7);
+            continue;
+        }
         for (int x0 = 0; x0 < nxl; x0 += kWave) {
             const bool live = x0 + c.lane < nxl;
             const int x = live ? xlist[x0 + c.lane] : 0;
@@ -1611,8 +1689,7 @@ __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, ui
     DevEnv *e = c.e;
     if (!e->have_request) {
         for (int i = c.lane; i < obs_dim; i += kWave) obs[i] = 0.f;
-        for (long long i = c.lane; i < nact; i += kWave) mask[i] = 0;
-        return;
+        return;                                            // the mask is zero-filled by the host before the launch
     }
     const int src = e->cur_src, dst = e->cur_dst;
     const double br = (double)e->cur_br;
@@ -1667,8 +1744,7 @@ __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, ui
         if (c.lane == 0) obs[3 + k] = path >= 0 ? (float)P.path_len_norm[path] : 0.f;   // :701-705
         if (path < 0) {
             for (int i = c.lane; i < M * 12; i += kWave) frow[i] = -1.f;
-            for (int i = c.lane; i < M * S; i += kWave) mrow[i] = 0;
-            continue;
+            continue;                                      // the mask rows stay zero (filled by the host)
         }
         PathRef p = load_path(c, path);
         const uint64_t free_ext = path_free_ext(c, p);
@@ -1690,76 +1766,90 @@ __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, ui
         }
         const int nb = wave_sum_i32(nb_l);
         const double len2 = (double)wave_sum_i32(len2_l);
+        STAMPW(c, 8);
         // ---- interferer field F(x) at the needed centres + valid starts per modulation (shared builder)
         build_field<R32>(c, p, free_ext, FieldLds{Fx, Vw, xlist, needx});
+        STAMPW(c, 9);
         // ---- per format of the window, best first (mod_list = reversed(modulations[start : start + M]), :716-717); the field
         // builder numbers its valid-start rows from the best of ALL formats: row fi = n_mods - 1 - m
         const double pw1 = G(P.path_w1)[path], pase = G(P.path_ase)[path];
+        // features that depend on the path only (:632-652, 660-663)
+        const double Sd = (double)S, S1 = (double)(S - 1), inv_S = 1.0 / Sd, inv_S1 = 1.0 / S1;
+        double mb = 0.0, sb = 0.0;
+        if (nb > 0) {
+            const double bm = (double)tot / nb;
+            mb = ((bm - 4.0) / 4.0) / 100.0;                             // :646-648
+            sb = sqrt(fmax(len2 / nb - bm * bm, 0.0)) / 100.0;
+        }
+        const float f_free = (float)(2.0 * ((double)tot - 0.5 * Sd) / Sd), f_free2 = (float)(2.0 * (((double)tot / Sd) - 0.5));
         for (int mi = 0; mi < M; mi++) {
             const int m = mod_start + M - 1 - mi;
             const int fi = Mall - 1 - m;
             const int n = uniform_i32(c.nreq[m]);
             float *f12 = frow + mi * 12;
-            uint8_t *mm = mrow + (long long)mi * S;
+            uint8_t *mm = mrow + (long long)mi * S;        // zero-filled by the host before the launch
             if (n <= 0 || n > S) {
                 if (c.lane == 0) for (int q = 0; q < 12; q++) f12[q] = (q == 4 || q == 10) ? (float)(2.0 * ((double)tot / S - 0.5)) : 0.f;
-                for (int i = c.lane; i < S; i += kWave) mm[i] = 0;
                 continue;
             }
-            const double thr = P.mod_thr[m], bw = P.slot_bw * n;
+            const double thr = P.mod_thr[m], bw = P.slot_bw * n, inv_thr = 1.0 / fabs(thr);
             const double self = pw1 * G(P.self_asinh)[n], nlic = G(P.nli_coef)[n] * c.rp[1];
-            int cnt_l = 0, sum_l = 0, sum2_l = 0, max_l = 0;
-            double os_l = 0.0, os2_l = 0.0, omax_l = -1e300;
+            // the valid starts of _get_candidates (:590), compacted: ascending slot indices in xlist (free again after the
+            // field was built), so that the per-candidate arithmetic runs on dense lanes
+            int cnt = 0;
+            const uint64_t vrow = Vw[fi * kMaxRowWords + min(c.lane, kMaxRowWords - 1)];    // lane i = word i
             for (int i = 0; i < W; i++) {
-                const uint64_t w = Vw[fi * kMaxRowWords + i];   // valid starts of _get_candidates (:590)
-                const int s = i * 64 + c.lane;
-                const bool valid = ((w >> c.lane) & 1ull) && s < S;
-                uint8_t bit = 0;
-                if (valid) {
-                    cnt_l += 1; sum_l += s; sum2_l += s * s; max_l = max(max_l, s);
-                    const double fc = P.f0 + (P.slot_bw * s) + (P.slot_bw * (n / 2.0));
-                    const double acc = (bw * fc * pase) * c.rp[0] + nlic * (self + Fx[2 * s + n]);
+                uint64_t w = readlane_u64(vrow, i);
+                if (i == (S >> 6)) w &= ~(1ull << (S & 63));              // the virtual slot S is not a start
+                if (i * 64 >= S) w = 0;
+                if (!w) continue;
+                const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(w >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)w, 0));
+                if ((w >> c.lane) & 1ull) xlist[cnt + pre] = (uint16_t)(i * 64 + c.lane);
+                cnt += __popcll((unsigned long long)w);
+            }
+            wave_sync();
+            STAMPW(c, 10);
+            int sum_l = 0, sum2_l = 0;
+            double os_l = 0.0, os2_l = 0.0, omax_l = -1e300;
+            for (int j0 = 0; j0 < cnt; j0 += kWave) {
+                if (j0 + c.lane < cnt) {
+                    const int s0 = xlist[j0 + c.lane];
+                    sum_l += s0; sum2_l += s0 * s0;
+                    const double fc = P.f0 + (P.slot_bw * s0) + (P.slot_bw * (n / 2.0));
+                    const double acc = (bw * fc * pase) * c.rp[0] + nlic * (self + Fx[2 * s0 + n]);
                     const double gsnr = -10.0 * log10(acc);
-                    const double nv = rint(((gsnr - thr) / fabs(thr)) * 1e10) / 1e10;   // np.round(x, 10), osnr.pyx:368
+                    // np.round((gsnr - thr) / abs(thr), 10), osnr.pyx:368 (reciprocals instead of the two divisions: the
+                    // value is reported as float32, and the sign test below could only differ within 1e-16 of -0.5e-10)
+                    const double nv = rint(((gsnr - thr) * inv_thr) * 1e10) * 1e-10;
                     os_l += nv; os2_l += nv * nv; omax_l = fmax(omax_l, nv);
-                    bit = nv >= 0.0 ? 1 : 0;                                             // :759-763
+                    if (nv >= 0.0) mm[s0] = 1;                                           // :759-763
                 }
-                if (s < S) mm[s] = bit;
             }
-            const int cnt = wave_sum_i32(cnt_l);
+            const int smax = cnt > 0 ? (int)xlist[cnt - 1] : 0;          // ascending: the last one
+            wave_sync();                                                 // xlist is rewritten for the next format
+            STAMPW(c, 11);
             const double ssum = (double)wave_sum_i32(sum_l), ssum2 = (double)wave_sum_i32(sum2_l);
-            const int smax = wave_max_i32(max_l);
             const double osum = wave_sum(os_l), osum2 = wave_sum(os2_l), omax = wave_max_f64(omax_l);
-            if (c.lane == 0) {
-                const double Sd = (double)S, S1 = (double)(S - 1);
-                double mean_s = 0.0, std_s = 0.0, om = 0.0, ov = 0.0, best = 0.0;
-                if (cnt > 0) {
-                    mean_s = ssum / cnt;
-                    std_s = sqrt(fmax(ssum2 / cnt - mean_s * mean_s, 0.0));
-                    om = osum / cnt;
-                    ov = fmax(osum2 / cnt - om * om, 0.0);
-                    best = fmax(omax, 0.0);                              // osnr_best starts at 0.0 (:604,622)
-                }
-                double mb = 0.0, sb = 0.0;
-                if (nb > 0) {
-                    double bm = (double)tot / nb;
-                    mb = ((bm - 4.0) / 4.0) / 100.0;                     // :646-648
-                    sb = sqrt(fmax(len2 / nb - bm * bm, 0.0)) / 100.0;
-                }
-                const double adj = ((double)n - 5.5) / 3.5;
-                f12[0] = (float)((double)cnt / Sd);
-                f12[1] = (float)(mean_s / S1);
-                f12[2] = (float)(std_s / S1);
-                f12[3] = (float)(adj > 0.0 ? adj : 0.0);
-                f12[4] = (float)(2.0 * ((double)tot - 0.5 * Sd) / Sd);
-                f12[5] = (float)mb;
-                f12[6] = (float)sb;
-                f12[7] = (float)best;
-                f12[8] = (float)om;
-                f12[9] = (float)ov;
-                f12[10] = (float)(2.0 * (((double)tot / Sd) - 0.5));
-                f12[11] = (float)((double)smax / S1);
+            STAMPW(c, 12);
+            double mean_s = 0.0, std_s = 0.0, om = 0.0, ov = 0.0, best = 0.0;
+            if (cnt > 0) {
+                const double inv_cnt = 1.0 / (double)cnt;
+                mean_s = ssum * inv_cnt;
+                std_s = sqrt(fmax(ssum2 * inv_cnt - mean_s * mean_s, 0.0));
+                om = osum * inv_cnt;
+                ov = fmax(osum2 * inv_cnt - om * om, 0.0);
+                best = fmax(omax, 0.0);                                  // osnr_best starts at 0.0 (:604,622)
             }
+            const double adj = ((double)n - 5.5) / 3.5;
+            // lane q stores feature q (one store instruction); a select chain, not a divergent switch
+            const float fv[12] = {(float)((double)cnt * inv_S), (float)(mean_s * inv_S1), (float)(std_s * inv_S1),
+                                  (float)(adj > 0.0 ? adj : 0.0), f_free, (float)mb, (float)sb, (float)best, (float)om, (float)ov,
+                                  f_free2, (float)((double)smax * inv_S1)};
+            float v = fv[0];
+#pragma unroll
+            for (int q = 1; q < 12; q++) v = c.lane == q ? fv[q] : v;
+            if (c.lane < 12) f12[c.lane] = v;
+            STAMPW(c, 13);
         }
     }
 }

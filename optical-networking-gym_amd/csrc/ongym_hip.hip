@@ -120,8 +120,11 @@ __global__ __launch_bounds__(64) void k_reset(const Params *__restrict__ Pp, con
     store_state(c);
 }
 
+#ifndef ONGYM_OBS_WAVES
+#define ONGYM_OBS_WAVES 3
+#endif
 template <bool R32>
-__global__ __launch_bounds__(64) void k_observe(const Params *__restrict__ Pp, float *obs, uint8_t *mask) {
+__global__ __launch_bounds__(64, ONGYM_OBS_WAVES) void k_observe(const Params *__restrict__ Pp, float *obs, uint8_t *mask) {
     extern __shared__ __align__(16) unsigned char smem[];
     const Params &P = *Pp;
     Ctx c(P);
@@ -132,16 +135,30 @@ __global__ __launch_bounds__(64) void k_observe(const Params *__restrict__ Pp, f
     c.gn_skips = 0;
     c.paths_tried = 0; c.path_hops = 0; c.active_sum = 0;
     ctx_bind(c, smem);
+#ifdef ONGYM_STAMPS
+    for (int i = 0; i < ONGYM_NSTAMPS; i++) c.stamp_acc[i] = 0;
+    c.stamp_last = __builtin_amdgcn_s_memtime();
+#endif
     load_state(c);
+    STAMPW(c, 0);
     double *Fx = reinterpret_cast<double *>(smem + lds_bytes(P));
     const size_t obs_dim = 3 + P.k_paths + (size_t)P.k_paths * P.n_mods_consider * 12;
     const size_t nact = (size_t)P.k_paths * P.n_mods_consider * P.n_slots + 1;
-    // extra LDS of the observation kernel: Fx f64[2S+2] | Vw u64[8*16] | xlist u16[2S+2] | needx u8[2S+2]
-    uint64_t *Vw = reinterpret_cast<uint64_t *>(Fx + 2 * P.n_slots + 2);
-    uint16_t *xlist = reinterpret_cast<uint16_t *>(Vw + kMaxMods * kMaxRowWords);
-    uint8_t *needx = reinterpret_cast<uint8_t *>(xlist + 2 * P.n_slots + 2);
+    // extra LDS of the observation kernel: Fx f64[2S+2] | xlist u16[2S+2] | Vw u64[8*16] | needx u8[2S+2].  The observation
+    // never looks at the release times, so Vw and needx take their place in the state block when they fit
+    // (observe_lds on the host makes the same choice).
+    uint16_t *xlist = reinterpret_cast<uint16_t *>(Fx + 2 * P.n_slots + 2);
+    uint64_t *Vw = obs_alias_sr(P) ? reinterpret_cast<uint64_t *>((reinterpret_cast<uintptr_t>(c.sr) + 7) & ~(uintptr_t)7)
+                                   : reinterpret_cast<uint64_t *>((reinterpret_cast<uintptr_t>(xlist + 2 * P.n_slots + 2) + 7) & ~(uintptr_t)7);
+    uint8_t *needx = reinterpret_cast<uint8_t *>(Vw + kMaxMods * kMaxRowWords);
+    wave_sync();
     c.fl = FieldLds{Fx, Vw, xlist, needx};
     observe_env<R32>(c, Fx, Vw, xlist, needx, obs + (size_t)c.replica * obs_dim, mask + (size_t)c.replica * nact);
+#ifdef ONGYM_STAMPS
+    STAMPW(c, 15);
+    if (c.lane == 0 && P.dbg)
+        for (int i = 0; i < ONGYM_NSTAMPS; i++) atomicAdd(&P.dbg[i], c.stamp_acc[i]);
+#endif
 }
 
 __global__ void k_seed(Params P, uint64_t seed, uint64_t replica_base) {
@@ -556,11 +573,22 @@ static int build(ongym_env *env, const ongym_config *c) {
     if ((rc = upload(env, c->node_cum, (size_t)N, &P.node_cum))) return rc;
     if (c->path_len_norm && (rc = upload(env, c->path_len_norm, (size_t)NP, &P.path_len_norm))) return rc;
 
-    // ---- lean first-fit kernel (ongym_fast.hpp): eligibility and its two extra tables ----
+    // the pair table once more with a row pitch of 2048 entries (index = row << 11 | distance: one address instruction);
+    // used by the lean first-fit kernel and by the observation field builder
+    if (!host_tab.empty() && P.tab_stride < kTabPitch && (size_t)P.tab_nmax * kTabPitch * 16 <= ((size_t)64 << 20)) {
+        std::vector<double> t2((size_t)P.tab_nmax * kTabPitch * 2, 0.0);
+        for (int nk = 0; nk < P.tab_nmax; nk++)
+            for (int d = 0; d < P.tab_stride; d++) {
+                t2[((size_t)nk * kTabPitch + d) * 2] = host_tab[(size_t)nk * P.tab_stride + d].x;
+                t2[((size_t)nk * kTabPitch + d) * 2 + 1] = host_tab[(size_t)nk * P.tab_stride + d].y;
+            }
+        if ((rc = upload(env, t2.data(), t2.size(), &P.pair_tab2k))) return rc;
+    }
+    // ---- lean first-fit kernel (ongym_fast.hpp): eligibility and its path table ----
     {
         bool ok = uniform && P.ase_shortcut && !P.track_ids && !P.measure_disruptions && c->bit_rate_mode == 0 &&
                   P.n_mods_consider == M &&
-                  c->n_bit_rates <= 8 && E <= 52 && N <= 64 && P.tab_stride < kTabPitch && !host_tab.empty();
+                  c->n_bit_rates <= 8 && E <= 52 && N <= 64 && P.pair_tab2k != nullptr;
         const char *force = std::getenv("ONGYM_FORCE_GENERIC");
         if (force && force[0] == '1') ok = false;
         int max_n = 0;
@@ -585,13 +613,6 @@ static int build(ongym_env *env, const ongym_config *c) {
             const PathRec *d_recs = nullptr;
             if ((rc = upload(env, recs.data(), recs.size(), &d_recs))) return rc;
             P.path_rec = d_recs;
-            std::vector<double> t2((size_t)P.tab_nmax * kTabPitch * 2, 0.0);
-            for (int nk = 0; nk < P.tab_nmax; nk++)
-                for (int d = 0; d < P.tab_stride; d++) {
-                    t2[((size_t)nk * kTabPitch + d) * 2] = host_tab[(size_t)nk * P.tab_stride + d].x;
-                    t2[((size_t)nk * kTabPitch + d) * 2 + 1] = host_tab[(size_t)nk * P.tab_stride + d].y;
-                }
-            if ((rc = upload(env, t2.data(), t2.size(), &P.pair_tab2k))) return rc;
             env->fast_ok = true; env->fast_m64 = m64; env->fast_lds = flds;
             // gfx950 hands out LDS in 1280-byte granules (160 KiB / 128; measured: 8160 B per workgroup gave 18 workgroups per
             // CU, 7648 B gave 20): pick the instantiation whose register budget matches the replicas the LDS admits
@@ -867,6 +888,13 @@ int ongym_reset_episode_counters(ongym_env *env, const uint8_t *mask) {
     return ONGYM_OK;
 }
 
+static size_t observe_lds(const ongym_env *env) {   // k_observe: state block + Fx, xlist (+ Vw, needx unless they alias svc_r)
+    const Params &P = env->P;
+    size_t b = env->lds + ((size_t)2 * P.n_slots + 2) * (sizeof(double) + 2) + 8;
+    if (!obs_alias_sr(P)) b += kMaxMods * kMaxRowWords * 8 + (size_t)2 * P.n_slots + 2 + 8;
+    return (b + 15) & ~(size_t)15;
+}
+
 static size_t field_lds(const ongym_env *env) {   // k_observe / highest-SNR k_run: state block + Fx, Vw, xlist, needx
     const Params &P = env->P;
     return ((env->lds + ((size_t)2 * P.n_slots + 2) * (sizeof(double) + 2 + 1) + kMaxMods * kMaxRowWords * 8) + 15) & ~(size_t)15;
@@ -1010,7 +1038,7 @@ int ongym_observe(ongym_env *env, float *obs, uint8_t *mask) {
     const size_t obs_dim = 3 + P.k_paths + (size_t)P.k_paths * P.n_mods_consider * 12;
     const size_t nact = (size_t)P.k_paths * P.n_mods_consider * P.n_slots + 1;
     const size_t B = (size_t)P.batch;
-    const size_t lds = field_lds(env);
+    const size_t lds = observe_lds(env);
     if (lds > 64 * 1024) {
         HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_observe<true>), lds));
         HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_observe<false>), lds));
@@ -1025,6 +1053,7 @@ int ongym_observe(ongym_env *env, float *obs, uint8_t *mask) {
         }
         d_obs = env->d_obs; d_mask = env->d_obsmask;
     }
+    HIP_TRY(env, hipMemsetAsync(d_mask, 0, B * nact, env->stream));     // k_observe only sets the ones
     HIP_TRY(env, hipEventRecord(env->ev0, env->stream));
     if (P.rec32) hipLaunchKernelGGL(k_observe<true>, dim3(P.batch), dim3(64), lds, env->stream, env->d_P, d_obs, d_mask);
     else hipLaunchKernelGGL(k_observe<false>, dim3(P.batch), dim3(64), lds, env->stream, env->d_P, d_obs, d_mask);
