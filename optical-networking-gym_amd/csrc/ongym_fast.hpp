@@ -177,6 +177,12 @@ __device__ __forceinline__ void fast_refill(const Params &P, const DevEnv *ge, u
 template <bool M64, bool REC, int ENT>
 __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step_rec *out, unsigned char *smem) {
     ONGYM_NO_CONTRACT
+#ifdef ONGYM_STAMPS
+    unsigned long long stamp_acc[ONGYM_NSTAMPS] = {0}, stamp_last = __builtin_amdgcn_s_memtime();
+#define FSTAMP(idx) do { __builtin_amdgcn_s_waitcnt(0); unsigned long long _t = __builtin_amdgcn_s_memtime(); stamp_acc[idx] += _t - stamp_last; stamp_last = _t; } while (0)
+#else
+#define FSTAMP(idx) do { } while (0)
+#endif
     const int lane = threadIdx.x, replica = blockIdx.x;
     const int E = P.n_links, RW = P.row_words * 2, C = P.capacity, S = P.n_slots, M = P.n_mods, K = P.k_paths, N = P.n_nodes;
     DevEnv *const ge = P.env + replica;
@@ -271,6 +277,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         cur_bi = hit ? __builtin_ctzll(hit) : 0;
     }
     int cur_p0 = uniform_i32(KC(P.pair_paths)[(cur_src * N + cur_dst) * K]);
+    const __attribute__((address_space(4))) PathRec *const path_recs = KC(reinterpret_cast<const PathRec *>(P.path_rec));
     // launch deltas
     int d_pops = 0, d_acc = 0, d_steps = 0, d_evals = 0, d_skips = 0, d_paths = 0, d_hops = 0, d_flags = 0, d_episodes = 0;
     unsigned long long d_active_sum = 0;
@@ -370,7 +377,6 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
     };
 
     const char __attribute__((address_space(1))) *const tab = (const char __attribute__((address_space(1))) *)P.pair_tab2k;
-    const __attribute__((address_space(4))) PathRec *const path_recs = KC(reinterpret_cast<const PathRec *>(P.path_rec));
 
     if (!uniform_i32(ge->have_request)) {            // never reset: every step is a no-op (same as k_run)
         if (lane == 0) {
@@ -385,6 +391,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         return;
     }
 
+    FSTAMP(11);
     for (int it = 0; it < nsteps; ++it) {
         // ================= policy: heuristic_shortest_available_path_first_fit_best_modulation =========================
         int ch_k = -1, ch_m = 0, ch_slot = 0, ch_n = 0, ch_path = -1;
@@ -393,6 +400,8 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         for (int k = 0; k < K; k++) {
             const int path = k == 0 ? cur_p0 : uniform_i32(KC(P.pair_paths)[(cur_src * N + cur_dst) * K + k]);
             if (path < 0) break;
+            // (fetching the first route's record already when the request is popped was measured 2.4 % SLOWER: eight more
+            //  live SGPRs across the departures scan cost more than the scalar-load latency they hide)
             const PathRec pr = load_path_rec(path_recs, path);
             d_paths++; d_hops += pr.hops;
             // modulations whose lower bound at slot 0 already fails cannot pass at any slot
@@ -404,9 +413,11 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             //  dB-domain test rejects anything above lim: the skipped evaluation would have failed)
             uint32_t feas = (uint32_t)(__ballot(lb < t_lim_hi) >> (8 * cur_bi)) & 0xFFu;
             d_skips += M - __popc(feas);            // modulations settled by the bound (statistics only)
+            FSTAMP(0);
             if (!feas) continue;
             const uint64_t pmask = M64 ? ((uint64_t)pr.mask_lo | ((uint64_t)(pr.mask_hi & 0xFFFFFu) << 32)) : (uint64_t)pr.mask_lo;
             uint32_t runs = path_and(pmask);
+            FSTAMP(1);
             int r = 1, L = -1;
             uint32_t e_c2k[ENT], e_key4[ENT];
             double e_w1[ENT], e_pw2[ENT];
@@ -419,6 +430,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                 if (n + 1 < r) { runs = path_and(pmask); r = 1; }     // slot counts normally grow as the modulation index falls
                 runs = run_and32(runs, r, n + 1);
                 const int first = first_set32(runs);
+                FSTAMP(2);
                 if (first < 0) continue;
                 if (L < 0) {
                     // ---- pass 1: interferers of this path -> LDS list -> registers (first 64*ENT of them)
@@ -437,6 +449,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                         L += n0 + __popcll((unsigned long long)bal1);
                     }
                     wave_sync();
+                    FSTAMP(3);
 #pragma unroll
                     for (int e = 0; e < ENT; e++) {
 #ifndef ONGYM_X_PREP_FLAT
@@ -489,6 +502,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                 }
 #endif
                 // ---- pass 2: 1/GSNR of (path, first, n) ----
+                FSTAMP(4);
                 const uint32_t c2 = (uint32_t)(2 * first + n);
                 double part = 0.0;
                 {
@@ -538,6 +552,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                         ok = (int)((db >> q) & 1ull);
                     }
                 }
+                FSTAMP(5);
                 if (ok) {
                     ch_k = k; ch_m = m; ch_slot = first; ch_n = n; ch_path = path;
                     ch_mask = pmask;
@@ -598,6 +613,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             }
         }
         d_steps++;
+        FSTAMP(6);
 
         ongym_step_rec *const recp = REC ? out + (size_t)it * P.batch + replica : nullptr;
         if (REC) {
@@ -647,10 +663,13 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         }
 
         // ================= _next_service (:1067-1122): next request, then the departures it triggers ==================
+        FSTAMP(10);
         pop_request();
+        FSTAMP(7);
         for (int ch = ((active + kWave - 1) / kWave) - 1; ch >= 0; ch--) {
             const float r = rr[ch * kWave + lane];                          // unused entries hold +inf
             uint64_t bal = __ballot(r <= v_at);
+            FSTAMP(8);
             while (bal) {
                 const int ln = 63 - __builtin_clzll(bal);                   // highest index first: the hole is filled by a keeper
                 bal &= ~(1ull << ln);
@@ -673,6 +692,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                 if (M64) lds_write_lane0_b32(a2_base + (uint32_t)last * 4u, 0u);
                 active = last;
                 wave_sync();
+                FSTAMP(9);
             }
         }
         d_active_sum += (unsigned long long)active;
@@ -711,6 +731,12 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             P.svc_a[off + i] = ga; P.svc_b[off + i] = gb; P.svc_r[off + i] = rr[i];
         }
     }
+    FSTAMP(12);
+#ifdef ONGYM_STAMPS
+    if (lane == 0 && P.dbg)
+        for (int i = 0; i < ONGYM_NSTAMPS; i++) atomicAdd(&P.dbg[i], stamp_acc[i]);
+#endif
+#undef FSTAMP
 }
 
 }  // namespace ongym

@@ -1031,7 +1031,7 @@ int ongym_step_actions(ongym_env *env, const int32_t *actions, ongym_step_rec *o
 int ongym_observe(ongym_env *env, float *obs, uint8_t *mask) {
     if (!env || !obs || !mask) return env ? fail_arg(env, "null obs/mask") : ONGYM_E_ARG;
     const Params &P = env->P;
-    if (!P.path_len_norm || !(P.max_bit_rate > 0)) return fail_arg(env, "observation needs path_len_norm and max_bit_rate (discrete bit rates)");
+    if (!P.path_len_norm || !(P.max_bit_rate > 0)) return fail_arg(env, "observation needs path_len_norm and max_bit_rate = max(bit_rates)");
     if (!P.uniform_alpha) return fail_arg(env, "observation kernel needs uniform attenuation", ONGYM_E_LIMIT);
     if (std::fabs(P.slot_bw - P.channel_width * 1e9) > 1e-6 * P.slot_bw) return fail_arg(env, "observation needs slot_bandwidth == channel_width*1e9");
     HIP_TRY(env, hipSetDevice(env->cfg.device));

@@ -167,7 +167,9 @@ class ConfigHolder:
         # observation(): route lengths normalised by min/max LINK length (qrmsa.pyx:692-705), max(bit_rates) (:679)
         lo, hi = float(np.min(t.link_length)), float(np.max(t.link_length))
         c.path_len_norm = f64("path_len_norm", [(x - lo) / (hi - lo) if hi != lo else 0.0 for x in t.path_length])
-        c.max_bit_rate = float(np.max(rates)) if bit_rate_selection == "discrete" else 0.0
+        # observation() normalises by max(self.bit_rates) whatever the selection mode (qrmsa.pyx:679, 688): in "continuous"
+        # mode that is the max of the (otherwise unused) bit_rates tuple
+        c.max_bit_rate = float(np.max(np.asarray(bit_rates, np.float64))) if len(bit_rates) else 0.0
         for name in ("rlp", "rload", "rmargin"):
             if name in keep and len(keep[name]) != batch:
                 raise ValueError("per-replica override arrays must have `batch` entries")

@@ -96,9 +96,6 @@ class QRMSAEnv:
                  bands: object = None, device: int = 0, capacity: int = 1024, sync_views: bool = True,
                  requests: Optional[np.ndarray] = None):
         self.gen_observation = bool(gen_observation)
-        if gen_observation and bit_rate_selection != "discrete":
-            raise NotImplementedError("gen_observation=True needs discrete bit rates (the reference's observation() reads "
-                                      "max(bit_rates), qrmsa.pyx:679)")
         self.defragmentation, self.n_defrag_services = bool(defragmentation), int(n_defrag_services)
         if bands and gen_observation:
             raise NotImplementedError("bands together with gen_observation=True is not built yet")

@@ -144,10 +144,13 @@ def test_step_errors_like_the_reference():
     assert reward == -6.0 and info["chosen_path_index"] == -1 and sim.current_service is not cur
 
 
-def test_unbuilt_features_fail_loudly():
+def test_reference_defaults_and_narrow_codec_construct():
     topology = get_topology(bundled_topology_path("nsfnet_chen.txt"), None, jocn_modulations(), 80, 0.2, 4.5, 5)
-    with pytest.raises(NotImplementedError):
-        QRMSAEnvWrapper(topology=topology, load=300, gen_observation=True)
+    # the reference's own defaults: continuous bit rates (25..100) and gen_observation=True (qrmsa.pyx:206-237)
+    dflt = QRMSAEnvWrapper(topology=topology, load=300)
+    obs, info = dflt.reset()
+    assert obs.shape == (368,) and info["mask"].shape == (9601,) and info["mask"][-1] == 1 and info["mask"][:-1].any()
+    assert 0.25 <= obs[0] <= 1.0            # bit rate / max(bit_rates) with bit_rates = (10, 40, 100)
     narrow = QRMSAEnvWrapper(topology=topology, load=300, gen_observation=False, modulations_to_consider=3)
     assert narrow.env.action_space.n == 5 * 3 * 320 + 1 and narrow.env.reject_action == 5 * 3 * 320   # qrmsa.pyx:313, 319-321
     assert narrow.env.encoded_decimal_to_array(1 * 3 * 320 + 2 * 320 + 7) == [1, 3, 7]                # window 5, 4, 3

@@ -121,6 +121,29 @@ def test_observation_vs_oracle_random_states(topo, S, load):
     assert mask[:, -1].all() and mask[:, :-1].any()
 
 
+def test_observation_continuous_bit_rates_vs_oracle():
+    """bit_rate_selection="continuous" (randint bit rates, slot counts by ceil): the observation normalises the bit rate by
+    max(bit_rates) of the otherwise unused tuple (qrmsa.pyx:679, 688); device vs oracle on loaded states."""
+    B = 8
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=256, capacity=1024, load=500,
+              bit_rate_selection="continuous", bit_rates=(10, 40, 100), bit_rate_lower_bound=25, bit_rate_higher_bound=300,
+              auto_reset=True)
+    holder = nat.ConfigHolder(golden_tables("nsfnet"), batch=B, **kw)
+    assert holder.struct.max_bit_rate == 100.0
+    env = BatchedQRMSAEnv(tables=golden_tables("nsfnet"), batch_size=B, **kw)
+    env.seed(21); env.reset()
+    env.step_policy(380, record=False)
+    obs, mask = env.observe()
+    pl = np.ctypeslib.as_array(holder.struct.path_len_norm, shape=(holder.struct.n_paths,))
+    for r in range(B):
+        o = OracleEnv(holder, replica=r)
+        o.seed(21); o.reset(); o.run_first_fit(380)
+        want_obs, want_mask = o.observe(pl, holder.struct.max_bit_rate)
+        np.testing.assert_array_equal(mask[r], want_mask, err_msg=f"mask replica {r}")
+        np.testing.assert_allclose(obs[r], want_obs, rtol=2e-6, atol=2e-7, err_msg=f"obs replica {r}")
+    assert obs[:, 0].max() > 1.0        # a 300 Gb/s request over max(bit_rates) = 100
+
+
 def test_masked_actions_are_accepted_by_step():
     """every action the mask allows is feasible: stepping it never raises the QoT error / retry."""
     meta, d = load_traj("obs_nsfnet320_dense")

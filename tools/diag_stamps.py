@@ -18,6 +18,10 @@ import numpy as np  # noqa: E402
 import bench  # noqa: E402
 from optical_networking_gym.envs.batched import BatchedQRMSAEnv  # noqa: E402
 
+FAST_NAMES = ["0 path record + bound prefilter", "1 path AND", "2 modulation loop: run-AND + first_set", "3 interferer list build",
+              "4 interferer cache (prep)", "5 GN evaluation (gather, sum, test)", "6 accept: mark, record, counters / reject flags",
+              "7 pop request (+ refill)", "8 release scan", "9 departures", "10 record / terminal", "11 load_state", "12 store_state",
+              "13 -", "14 -", "15 -"]
 NAMES = ["0 request+nslots", "1 path load+AND", "2 run_and/first_set", "3 gn_build_list", "4 gn_eval", "5 mark_links",
          "6 lane0 bookkeeping+draw", "7 release_due", "8 load_state", "9 store_state",
          "10 gn: self term/setup", "11 gn: list+record LDS", "12 gn: pair-table gather", "13 gn: link-weight loop",
@@ -34,7 +38,7 @@ env = BatchedQRMSAEnv(tables=bench.build_tables(wl["topology"]), modulations=ben
                       episode_length=1000, auto_reset=True, load=wl["load"], bit_rate_selection="discrete",
                       bit_rates=wl["bit_rates"])
 env.seed(1); env.reset()
-env.step_policy(750, record=False)
+env.step_policy(1000, record=False)
 out = (C.c_ulonglong * 16)()
 env.lib.ongym_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
 env.lib.ongym_debug_stamps(env._h, out)
@@ -44,7 +48,7 @@ ms = env.last_kernel_ms()
 env.lib.ongym_debug_stamps(env._h, out)
 v = np.array(list(out)[:16], np.float64)
 tot = v.sum()
-print(f"kernel {ms:.2f} ms; {args.batch * args.steps / ms / 1e3:.3e} steps/s (stamped build)")
-for n, x in zip(NAMES, v):
+print(f"kernel {ms:.2f} ms; {args.batch * args.steps / ms * 1e3:.3e} steps/s (stamped build), {env.occupancy()}")
+for n, x in zip(FAST_NAMES if env.occupancy()["lean_kernel"] else NAMES, v):
     print(f"  {n:28s} {100 * x / tot:5.1f} %   {x / (args.batch * args.steps):9.0f} cycles/step/wave")
 print(f"  total {tot / (args.batch * args.steps):.0f} cycles per env-step per wave")
