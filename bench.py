@@ -42,6 +42,9 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, a wave64 VALU instruction takes 2 cycles on its SIMD, 2.4 GHz max clock
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
+# scalar ALU: one instruction per SIMD every ~4 cycles, whatever the number of waves (measured: tools/ubench/issue_rates.hip,
+# profiles/r02_issue_rates_ubench.txt: 4.3 cycles per s_add_u32 per SIMD at 2..8 waves/SIMD)
+SALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0
 # reference (Cython) throughput measured in the build container, BASELINE.md §2 / SURVEY §6 (cannot travel to the GPU box)
 REFERENCE_MEASURED = {
     "nsfnet320": {"steps_per_s_1core": 348.0, "steps_per_s_8procs": 2178.0},
@@ -241,7 +244,9 @@ def main():
             valu = pmc.get("valu_per_env_step")
             if valu is not None:
                 rate = valu * (float(local_batch) * spl / avg_launch_s)
-                issue = {"bound": "valu-issue", "valu_wave_insts_per_env_step": valu,
+                salu = pmc.get("salu_per_env_step")
+                salu_rate = salu * (float(local_batch) * spl / avg_launch_s) if salu is not None else None
+                issue = {"bound": "instruction issue (scalar + vector ALU)", "valu_wave_insts_per_env_step": valu,
                          "salu_wave_insts_per_env_step": pmc.get("salu_per_env_step"),
                          "lds_wave_insts_per_env_step": pmc.get("lds_per_env_step"),
                          "smem_wave_insts_per_env_step": pmc.get("smem_per_env_step"),
@@ -249,6 +254,9 @@ def main():
                          "valu_busy_frac": pmc.get("valu_busy_frac"), "wait_any_frac": pmc.get("wait_any_frac"),
                          "achieved": rate, "peak": VALU_ISSUE_PEAK, "unit": "VALU wave-insts/s",
                          "frac": rate / VALU_ISSUE_PEAK,
+                         "salu_achieved": salu_rate, "salu_peak": SALU_ISSUE_PEAK,
+                         "salu_frac": salu_rate / SALU_ISSUE_PEAK if salu_rate is not None else None,
+                         "wave_cycles_per_env_step": pmc.get("wave_cycles_per_env_step"),
                          "source": pmc.get("source"), "note": "instruction counts per env-step from the tracked rocprofv3 "
                          "--pmc passes (separate runs); rate = counts x the env-step rate measured live in this run"}
         out = {
