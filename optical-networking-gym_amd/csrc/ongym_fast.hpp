@@ -174,7 +174,23 @@ __device__ __forceinline__ void fast_refill(const Params &P, const DevEnv *ge, u
     rq_pk = (uint32_t)src | ((uint32_t)dst << 6) | ((uint32_t)bi << 12) | ((uint32_t)(p0 + 1) << 15);
 }
 
-template <bool M64, bool REC, int ENT>
+// The same ring from a replayed trace (ongym_set_requests with bit rates of the configured table, checked on the host):
+// lane i holds trace entry base + i; `rq_iat` then carries the ABSOLUTE arrival time.  Entries past the end are never popped.
+__device__ __forceinline__ void fast_refill_trace(const Params &P, int replica, uint64_t base, int lane, float &rq_at, float &rq_ht,
+                                                  uint32_t &rq_pk) {
+    const long long idx = (long long)base + lane;
+    rq_at = 0.f; rq_ht = 0.f; rq_pk = 0;
+    if (idx < P.trace_n) {
+        const ongym_request q = P.trace[(long long)replica * P.trace_n + idx];
+        rq_at = q.arrival_time; rq_ht = q.holding_time;
+        int bi = 0;
+        for (int b = 0; b < P.n_bit_rates; b++) if ((float)G(P.bit_rates)[b] == q.bit_rate) bi = b;
+        const int p0 = G(P.pair_paths)[((int)q.source * P.n_nodes + (int)q.destination) * P.k_paths];
+        rq_pk = (uint32_t)q.source | ((uint32_t)q.destination << 6) | ((uint32_t)bi << 12) | ((uint32_t)(p0 + 1) << 15);
+    }
+}
+
+template <bool M64, bool REC, int ENT, bool TRACE>
 __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step_rec *out, unsigned char *smem) {
     ONGYM_NO_CONTRACT
 #ifdef ONGYM_STAMPS
@@ -285,7 +301,12 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
     float rq_iat, rq_ht;
     uint32_t rq_pk;
     int rq_pos = 0;
-    auto refill = [&]() { fast_refill(P, ge, req_base, lane, rq_iat, rq_ht, rq_pk); rq_pos = 0; };
+    auto refill = [&]() {
+        if (TRACE) fast_refill_trace(P, replica, req_base, lane, rq_iat, rq_ht, rq_pk);
+        else fast_refill(P, ge, req_base, lane, rq_iat, rq_ht, rq_pk);
+        rq_pos = 0;
+    };
+    bool have = true;           // a current request exists (a replayed trace can run out: every further step is a no-op)
     refill();
     wave_sync();
 
@@ -304,7 +325,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             ge->req_index = req_base + (uint64_t)rq_pos;
             s.current_time = (double)v_at;
             ge->cur_at = v_at; ge->cur_ht = cur_ht; ge->cur_br = brs[cur_bi]; ge->cur_src = cur_src; ge->cur_dst = cur_dst;
-            ge->cur_id = epp - 1; ge->have_request = 1;
+            ge->cur_id = epp - 1; ge->have_request = have ? 1 : 0;
             s.services_processed += d_pops; s.episode_services_processed = epp;
             s.services_accepted += d_acc; s.total_accepted += d_acc;
             s.rejected = erej;
@@ -329,8 +350,13 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
     // next request: pop the ring, advance the float32 clock (envs/qrmsa.pyx:1079-1111)
     auto pop_request = [&]() {
         if (rq_pos == kWave) { req_base += kWave; refill(); }
+        if (TRACE && (long long)(req_base + (uint64_t)rq_pos) >= P.trace_n) {      // trace exhausted (see draw_next)
+            have = false; d_flags |= ONGYM_F_NO_REQUEST;
+            return;
+        }
         const uint32_t pk = rl(rq_pk, rq_pos);
-        v_at = v_at + rlf(rq_iat, rq_pos);              // at = float32(current_time + expovariate)
+        if (TRACE) v_at = rlf(rq_iat, rq_pos);          // the trace carries absolute float32 arrival times
+        else v_at = v_at + rlf(rq_iat, rq_pos);         // at = float32(current_time + expovariate)
         cur_ht = rlf(rq_ht, rq_pos);
         rq_pos++;
         cur_src = pk & 63; cur_dst = (pk >> 6) & 63; cur_bi = (pk >> 12) & 7; cur_p0 = (int)(pk >> 15) - 1;
@@ -393,6 +419,15 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
 
     FSTAMP(11);
     for (int it = 0; it < nsteps; ++it) {
+        if (TRACE && !have) {           // no request source left: the step is a no-op (as in k_run)
+            if (REC && lane == 0) {
+                ongym_step_rec r;
+                memset(&r, 0, sizeof(r));
+                r.action = -1; r.route = r.modulation = r.slot = -1; r.flags = ONGYM_F_NO_REQUEST; r.active = active;
+                out[(size_t)it * P.batch + replica] = r;
+            }
+            continue;
+        }
         // ================= policy: heuristic_shortest_available_path_first_fit_best_modulation =========================
         int ch_k = -1, ch_m = 0, ch_slot = 0, ch_n = 0, ch_path = -1;
         uint64_t ch_mask = 0;

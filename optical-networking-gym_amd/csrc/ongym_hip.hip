@@ -97,10 +97,10 @@ __global__ __launch_bounds__(64, WAVES) void k_run(const Params *__restrict__ Pp
 
 // The lean fused first-fit kernel (ongym_fast.hpp).  M64: link masks need two words (32 < n_links <= 52);
 // ENT: interferers per lane cached in registers; WAVES: waves per SIMD the register allocation is bounded for.
-template <bool M64, bool REC, int ENT, int WAVES>
+template <bool M64, bool REC, int ENT, int WAVES, bool TRACE = false>
 __global__ __launch_bounds__(64, WAVES) void k_fast(const Params *__restrict__ Pp, int nsteps, ongym_step_rec *out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    fast_run<M64, REC, ENT>(*Pp, nsteps, out, smem);
+    fast_run<M64, REC, ENT, TRACE>(*Pp, nsteps, out, smem);
 }
 
 __global__ __launch_bounds__(64) void k_reset(const Params *__restrict__ Pp, const uint8_t *mask) {
@@ -314,10 +314,12 @@ struct ongym_env {
     float *d_obs = nullptr; uint8_t *d_obsmask = nullptr;   // lazily allocated staging for ongym_observe with host buffers
     int32_t *d_scratch_i = nullptr; size_t scratch_i_bytes = 0; double *d_scratch_d = nullptr;
     bool has_source = false;
+    std::vector<double> cfg_bit_rates;     // host copy of the discrete bit rates
     bool fast_ok = false;           // the configuration is eligible for k_fast (see fast_eligible)
     bool fast_m64 = false;
     int fast_waves = 4;             // waves per SIMD of the k_fast instantiation that runs (register budget 512 / waves)
-    bool trace_used = false;        // a replayed trace may have left records the lean codec cannot hold
+    bool trace_used = false;        // a trace the lean kernel cannot replay was installed: its records may not fit the lean codec
+    bool trace_fast_ok = false;     // the installed (host) trace only carries bit rates of the configured table
     size_t fast_lds = 0;
 };
 
@@ -425,6 +427,7 @@ static int build(ongym_env *env, const ongym_config *c) {
     P.f0 = c->frequency_start; P.slot_bw = c->slot_bandwidth; P.channel_width = c->channel_width;
     P.mean_holding = c->mean_holding_time;
     P.max_bit_rate = c->max_bit_rate;
+    if (c->bit_rate_mode == 0) env->cfg_bit_rates.assign(c->bit_rates, c->bit_rates + c->n_bit_rates);
     P.path_len_norm = nullptr;
     P.mean_holding_f = (float)c->mean_holding_time;
 
@@ -686,6 +689,9 @@ static int build(ongym_env *env, const ongym_config *c) {
         ONGYM_SET_FLDS((k_fast<false, false, 2, 4>)); ONGYM_SET_FLDS((k_fast<false, true, 2, 4>));
         ONGYM_SET_FLDS((k_fast<false, false, 2, 5>)); ONGYM_SET_FLDS((k_fast<false, true, 2, 5>));
         ONGYM_SET_FLDS((k_fast<true, false, 4, 3>)); ONGYM_SET_FLDS((k_fast<true, true, 4, 3>));
+        ONGYM_SET_FLDS((k_fast<false, false, 2, 4, true>)); ONGYM_SET_FLDS((k_fast<false, true, 2, 4, true>));
+        ONGYM_SET_FLDS((k_fast<false, false, 2, 5, true>)); ONGYM_SET_FLDS((k_fast<false, true, 2, 5, true>));
+        ONGYM_SET_FLDS((k_fast<true, false, 4, 3, true>)); ONGYM_SET_FLDS((k_fast<true, true, 4, 3, true>));
 #undef ONGYM_SET_FLDS
     }
     // scratch for queries / host-buffer I/O
@@ -773,7 +779,8 @@ int ongym_query_occupancy(ongym_env *env, int32_t *blocks_per_cu, int32_t *lds_b
     if (!env || !blocks_per_cu || !lds_bytes || !lean_kernel) return ONGYM_E_ARG;
     HIP_TRY(env, hipSetDevice(env->cfg.device));
     int nb = 0;
-    const bool lean = env->fast_ok && !env->trace_used && env->P.req_mode == kReqRng;
+    const bool lean = env->fast_ok && !env->trace_used &&
+                      (env->P.req_mode == kReqRng || (env->P.req_mode == kReqTrace && env->trace_fast_ok));
     if (lean) {
         if (env->fast_m64) HIP_TRY(env, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<true, false, 4, 3>, 64, env->fast_lds));
         else if (env->fast_waves == 5) HIP_TRY(env, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<false, false, 2, 5>, 64, env->fast_lds));
@@ -840,7 +847,19 @@ int ongym_set_requests(ongym_env *env, const ongym_request *reqs, int64_t n_per_
     }
     env->P.trace_n = n_per_replica;
     env->P.req_mode = kReqTrace;
-    env->trace_used = true;
+    // the lean kernel replays a trace whose bit rates all come from the configured discrete table (it addresses per-request
+    // constants by bit-rate index); anything else is the generic kernel's, for good (records may exceed the lean codec)
+    env->trace_fast_ok = false;
+    if (!env->cfg.io_device && env->fast_ok) {
+        bool ok = true;
+        for (size_t i = 0; i < n && ok; i++) {
+            bool hit = false;
+            for (int b = 0; b < env->P.n_bit_rates; b++) hit |= (float)env->cfg_bit_rates[(size_t)b] == reqs[i].bit_rate;
+            ok = hit;
+        }
+        env->trace_fast_ok = ok;
+    }
+    if (!env->trace_fast_ok) env->trace_used = true;
     env->has_source = true;
     { int rc = push_params(env); if (rc) return rc; }
     int threads = 256, blocks = (env->P.batch + threads - 1) / threads;
@@ -905,11 +924,14 @@ static int launch_run(ongym_env *env, int mode, int policy, int nsteps, const in
     HIP_TRY(env, hipEventRecord(env->ev0, env->stream));
     const dim3 grid(env->P.batch), block(64);
     if (mode == kModePolicyStep && policy == ONGYM_POLICY_FIRST_FIT && env->fast_ok && !env->trace_used &&
-        env->P.req_mode == kReqRng) {
-        // the lean kernel: same results, ~3x fewer issued instructions (ongym_fast.hpp)
+        (env->P.req_mode == kReqRng || (env->P.req_mode == kReqTrace && env->trace_fast_ok))) {
+        // the lean kernel: same results, half the issued instructions (ongym_fast.hpp)
+        const bool tr = env->P.req_mode == kReqTrace;
 #define ONGYM_LAUNCH_FAST(M64, ENT, WAVES)                                                                         \
     do {                                                                                                           \
-        if (d_out) hipLaunchKernelGGL((k_fast<M64, true, ENT, WAVES>), grid, block, env->fast_lds, env->stream, env->d_P, nsteps, d_out); \
+        if (tr && d_out) hipLaunchKernelGGL((k_fast<M64, true, ENT, WAVES, true>), grid, block, env->fast_lds, env->stream, env->d_P, nsteps, d_out); \
+        else if (tr) hipLaunchKernelGGL((k_fast<M64, false, ENT, WAVES, true>), grid, block, env->fast_lds, env->stream, env->d_P, nsteps, d_out);  \
+        else if (d_out) hipLaunchKernelGGL((k_fast<M64, true, ENT, WAVES>), grid, block, env->fast_lds, env->stream, env->d_P, nsteps, d_out); \
         else hipLaunchKernelGGL((k_fast<M64, false, ENT, WAVES>), grid, block, env->fast_lds, env->stream, env->d_P, nsteps, d_out);      \
     } while (0)
         if (env->fast_m64) ONGYM_LAUNCH_FAST(true, 4, 3);

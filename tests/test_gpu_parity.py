@@ -36,13 +36,19 @@ def assert_records_equal(got, want, ctx=""):
         np.testing.assert_allclose(got[f], want[f], rtol=GSNR_RTOL, err_msg=f"{ctx}: {f}")
 
 
-@pytest.mark.parametrize("tag", ALL_TRAJ)
-def test_first_fit_trajectory_vs_reference(tag):
+@pytest.mark.parametrize("tag,generic", [(t, g) for t in ALL_TRAJ for g in (False, True)])
+def test_first_fit_trajectory_vs_reference(tag, generic, monkeypatch):
     """Replays the reference's captured request trace; every step of the fused policy+step kernel must reproduce the
-    reference's action, slot, modulation, accept decision, reward, termination and GSNR."""
+    reference's action, slot, modulation, accept decision, reward, termination and GSNR.  Both kernels: the lean k_fast
+    (the benchmark's; it replays traces whose bit rates come from the configured table) and the generic k_run
+    (ONGYM_FORCE_GENERIC=1)."""
     meta, d = load_traj(tag)
+    if generic:
+        monkeypatch.setenv("ONGYM_FORCE_GENERIC", "1")
     env = make_env(meta, auto_reset=True)
     env.set_requests(traj_requests(d))
+    lean_expected = (not generic) and meta["bit_rate_selection"] == "discrete"
+    assert env.occupancy()["lean_kernel"] == lean_expected
     for _ in range(meta["initial_resets"]):
         env.reset()
     n = meta["n_steps"]
