@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Launch-power sweep of the JOCN benchmark (Sec. 4.A of the paper; reference: examples/JOCN_Benchmark_2024/
 graph_launch_power.py), batched: the 17 launch powers x R parallel simulations are replicas of ONE device environment.
-Heuristic indices are the reference's (graph_launch_power.py:106-128); all but 5 (full MSCL, plugin only) are fused on
-device.
+Heuristic indices are the reference's (graph_launch_power.py:106-128); all of them are fused on device.
 
     python examples/JOCN_Benchmark_2024/graph_launch_power.py -t nobel-eu.xml -e 1000 -s 1000 -l 200
 """
@@ -10,10 +9,10 @@ import argparse
 
 import numpy as np
 
-from jocn_common import load_topology, run_sweep, run_sweep_plugin
+from jocn_common import load_topology, run_sweep
 
 # reference index -> fused device policy id (include/ongym.h)
-FUSED = {1: 0, 2: 3, 3: 5, 4: 1, 6: 6, 7: 7, 8: 4, 9: 8, 10: 8}
+FUSED = {1: 0, 2: 3, 3: 5, 4: 1, 5: 11, 6: 6, 7: 7, 8: 4, 9: 8, 10: 8}
 
 
 def main():
@@ -27,7 +26,7 @@ def main():
     ap.add_argument("-mf", "--monitor_file_name", default="examples/JOCN_Benchmark_2024/results/simulation_results")
     ap.add_argument("-hi", "--heuristic_index", type=int, default=1, choices=[1, 2, 3, 4, 5, 6, 7, 8, 9, 10],
                     help="1 first fit, 2 lowest spectrum, 3 best-modulation load balancing, 4 load balancing best "
-                         "modulation, 5 MSCL (plugin), 6 MSCL simplified, 7 MSCL sequential, 8 load-balancing first fit, "
+                         "modulation, 5 MSCL, 6 MSCL simplified, 7 MSCL sequential, 8 load-balancing first fit, "
                          "9 PSR-C, 10 PSR-O")
     ap.add_argument("--slots", type=int, default=320)
     ap.add_argument("--seed", type=int, default=20)
@@ -39,13 +38,6 @@ def main():
                   bit_rates=(10, 40, 100, 400), capacity=1024)
     names = [f"{args.monitor_file_name}_{topology.graph['name']}_{lp}_{float(args.load)}.csv" for lp in launch_powers]
     points = [dict(launch_power_dbm=float(lp)) for lp in launch_powers]
-    if args.heuristic_index == 5:
-        from optical_networking_gym.heuristics.heuristics import heuristic_mscl
-        res = run_sweep_plugin(topology, heuristic_mscl, n_episodes=args.num_episodes, episode_length=args.episode_length,
-                               seed=args.seed, common=common, points=points, monitor_names=names)
-        for lp, b in zip(launch_powers, res):
-            print(f"Launch power: {lp:.1f} dBm, mean: {b.mean():.4f}")
-        return
     res = run_sweep(topology, n_episodes=args.num_episodes, episode_length=args.episode_length,
                     replicas_per_point=min(args.threads, args.num_episodes), seed=args.seed, common=common,
                     points=points, monitor_names=names, policy=FUSED[args.heuristic_index])

@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Load sweep of the JOCN benchmark (reference: examples/JOCN_Benchmark_2024/graph_load.py), batched: all loads x R
-parallel simulations are replicas of ONE device environment; heuristics 1 (first fit), 2 (highest SNR) and
-4 (load balancing best modulation) are fused on device, 3 (lowest fragmentation) runs as a plugin on one device-backed
-env per load (slow).
+parallel simulations are replicas of ONE device environment; heuristics 1 (first fit), 2 (highest SNR),
+3 (lowest fragmentation) and 4 (load balancing best modulation) are all fused on device.
 
     python examples/JOCN_Benchmark_2024/graph_load.py -t nobel-eu.xml -e 1000 -s 1000
 """
@@ -10,7 +9,7 @@ import argparse
 
 import numpy as np
 
-from jocn_common import load_topology, run_sweep, run_sweep_plugin
+from jocn_common import load_topology, run_sweep
 
 
 def get_loads(topology_name: str) -> np.ndarray:   # reference graph_load.py:17-29
@@ -29,8 +28,9 @@ def main():
     ap.add_argument("-s", "--episode_length", type=int, default=1000)
     ap.add_argument("-th", "--threads", type=int, default=25, help="parallel simulations (replicas) per load")
     ap.add_argument("-hi", "--heuristic_index", type=int, default=1, choices=[1, 2, 3, 4],
-                    help="1: first fit, 2: highest SNR, 4: load balancing best modulation (fused on device); "
-                         "3: lowest fragmentation (plugin)")
+                    help="1: first fit, 2: highest SNR, 3: lowest fragmentation, 4: load balancing best modulation "
+                         "(all fused on device; 3 rejects and flags the requests on which the reference raises its QoT "
+                         "ValueError, qrmsa.pyx:925-929)")
     ap.add_argument("-df", "--defragmentation", action="store_true", help="defragment after departures (qrmsa.pyx:1117-1119)")
     ap.add_argument("-nd", "--n_defrag_services", type=int, default=0)
     ap.add_argument("-mf", "--monitor_file_name", default="examples/JOCN_Benchmark_2024/results/load_episodes")
@@ -45,18 +45,10 @@ def main():
                   defragmentation=args.defragmentation, n_defrag_services=args.n_defrag_services)
     names = [f"{args.monitor_file_name}_{args.heuristic_index}_{topology.graph['name']}_{args.launch_power}_{float(ld)}.csv"
              for ld in loads]
-    if args.heuristic_index == 3:
-        from optical_networking_gym.heuristics.heuristics import heuristic_lowest_fragmentation
-        res = run_sweep_plugin(topology, heuristic_lowest_fragmentation, n_episodes=args.num_episodes,
-                               episode_length=args.episode_length, seed=args.seed, common=common,
-                               points=[dict(load=float(ld)) for ld in loads], monitor_names=names)
-        for ld, b in zip(loads, res):
-            print(f"Load: {ld} Erlang, episode_service_blocking_rate mean: {b.mean():.4f}")
-        return
     res = run_sweep(topology, n_episodes=args.num_episodes, episode_length=args.episode_length,
                     replicas_per_point=min(args.threads, args.num_episodes), seed=args.seed, common=common,
                     points=[dict(load=float(ld)) for ld in loads], monitor_names=names,
-                    policy={1: 0, 2: 2, 4: 1}[args.heuristic_index])
+                    policy={1: 0, 2: 2, 3: 10, 4: 1}[args.heuristic_index])
     for ld, b in zip(loads, res):
         print(f"Load: {ld} Erlang, episode_service_blocking_rate mean: {b.mean():.4f}")
 

@@ -50,7 +50,13 @@ enum {
     ONGYM_POLICY_PSR = 8,             /* heuristic_psr with its default coefficients, :1019-1119 */
     ONGYM_POLICY_EXACT_FIT = 9,       /* heuristic_exact_fit, :1121-1227 (asks for no guard slot: the step may answer
                                          with the occupied-slots penalty, retry = 1) */
-    ONGYM_POLICY_COUNT = 10
+    /* the two policies that score every candidate (one more instantiation, csrc/ongym_scored.hpp): */
+    ONGYM_POLICY_LOWEST_FRAGMENTATION = 10, /* heuristic_lowest_fragmentation, :330-414 (its request is sized slots + 1; if the
+                                               step's own GSNR check at `slots` then fails - the reference raises ValueError,
+                                               qrmsa.pyx:925-929 - the fused loop rejects the request with
+                                               ONGYM_F_QOT_ERROR | ONGYM_F_BLOCKED_OSNR and goes on) */
+    ONGYM_POLICY_MSCL = 11,                 /* heuristic_mscl, :647-749 (discrete bit rates only: the loss is summed over them) */
+    ONGYM_POLICY_COUNT = 12
 };
 
 /* ongym_step_rec.flags */

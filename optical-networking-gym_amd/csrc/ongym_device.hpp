@@ -97,6 +97,7 @@ struct Params {
     const double *pair_tab2k;       // the pair table with a row pitch of 2048 entries: [tab_nmax][2048][2]
     const double *bit_rates, *bit_rate_cum, *node_cum;
     const double *path_len_norm;    // [P] observation(): (length - min link) / (max link - min link)
+    const double *plogp;            // [S+1] (n/S)*log(n/S), n = 1..S: the Shannon-entropy terms of utils.pyx:61-79 (ongym_scored.hpp)
     double max_bit_rate;
     int mod_se[kMaxMods];
     double mod_thr[kMaxMods];

@@ -12,6 +12,7 @@
 
 #include "ongym_device.hpp"
 #include "ongym_fast.hpp"
+#include "ongym_scored.hpp"
 
 using namespace ongym;
 
@@ -73,8 +74,21 @@ __global__ __launch_bounds__(64, WAVES) void k_run(const Params *__restrict__ Pp
             if (POLICY == ONGYM_POLICY_HIGHEST_SNR) policy_highest_snr<R32>(c, src, dst, lp, mg, ch);
             else if (POLICY == ONGYM_POLICY_LOAD_BALANCING) policy_load_balancing<UA, R32>(c, src, dst, lp, mg, ch);
             else if (POLICY == kPolicyMisc) policy_misc<UA, R32>(c, policy_id, src, dst, mg, ch);
+            else if (POLICY == kPolicyScored)
+                policy_scored<UA, R32>(c, policy_id, src, dst, mg, ch, reinterpret_cast<int32_t *>(smem + ((lds_bytes(P) + 15) & ~(size_t)15)));
             else policy_first_fit<UA, R32>(c, src, dst, lp, mg, ch);
             outcome = ch.route >= 0 ? (ch.busy ? 2 : 0) : 1;
+            if (POLICY == kPolicyScored && mode == kModePolicyStep && ch.route >= 0) {
+                // `env.step(action)` evaluates the GN model itself, at the width the format needs (lowest fragmentation asked
+                // for one slot more): the reference raises ValueError if that fails (envs/qrmsa.pyx:925-929) — a fused
+                // episode rejects the request instead and flags it
+                outcome = evaluate_action<UA, R32>(c, src, dst, lp, mg, ch.action, ch);
+                if (outcome == 3) {
+                    outcome = 1;
+                    ch.action = P.k_paths * P.n_mods * P.n_slots; ch.route = -1; ch.mod = -1; ch.slot = -1; ch.n = 0;
+                    ch.flags = ONGYM_F_QOT_ERROR | ONGYM_F_BLOCKED_OSNR;
+                }
+            }
             // modulations_to_consider < n_mods: `env.step(action)` decodes the heuristic's action index with the window codec
             // (envs/qrmsa.pyx:801-834), which need not give back what the heuristic meant (heuristics.py:36-54 encodes formats
             // outside the window past the codec's range): do what the reference's loop does
@@ -575,6 +589,11 @@ static int build(ongym_env *env, const ongym_config *c) {
     if (c->bit_rate_mode != 0) P.n_bit_rates = 1;
     if ((rc = upload(env, c->node_cum, (size_t)N, &P.node_cum))) return rc;
     if (c->path_len_norm && (rc = upload(env, c->path_len_norm, (size_t)NP, &P.path_len_norm))) return rc;
+    {   // link_shannon_entropy_ (utils.pyx:61-79): p = block / total_slots; p * math.log(p) — CPython's math.log is this log()
+        std::vector<double> plogp((size_t)c->n_slots + 1, 0.0);
+        for (int n = 1; n <= c->n_slots; n++) { const double pr = (double)n / (double)c->n_slots; plogp[n] = pr * std::log(pr); }
+        if ((rc = upload(env, plogp.data(), plogp.size(), &P.plogp))) return rc;
+    }
 
     // the pair table once more with a row pitch of 2048 entries (index = row << 11 | distance: one address instruction);
     // used by the lean first-fit kernel and by the observation field builder
@@ -919,6 +938,8 @@ static size_t field_lds(const ongym_env *env) {   // k_observe / highest-SNR k_r
     return ((env->lds + ((size_t)2 * P.n_slots + 2) * (sizeof(double) + 2 + 1) + kMaxMods * kMaxRowWords * 8) + 15) & ~(size_t)15;
 }
 
+static size_t scored_lds(const ongym_env *env) { return ((env->lds + 15) & ~(size_t)15) + scored_lds_bytes(env->P.row_words); }
+
 static int launch_run(ongym_env *env, int mode, int policy, int nsteps, const int32_t *d_actions, int32_t *d_act_out,
                       uint8_t *d_flag_out, ongym_step_rec *d_out) {
     HIP_TRY(env, hipEventRecord(env->ev0, env->stream));
@@ -964,6 +985,13 @@ static int launch_run(ongym_env *env, int mode, int policy, int nsteps, const in
         } else if (policy == ONGYM_POLICY_LOAD_BALANCING) {
             if (env->P.rec32) ONGYM_LAUNCH_DEFRAG(true, ONGYM_POLICY_LOAD_BALANCING, env->lds);
             else ONGYM_LAUNCH_DEFRAG(false, ONGYM_POLICY_LOAD_BALANCING, env->lds);
+        } else if (policy >= ONGYM_POLICY_LOWEST_FRAGMENTATION) {
+            if (scored_lds(env) > 64 * 1024) {
+                HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<true, true, 4, kPolicyScored, true>), scored_lds(env)));
+                HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<true, false, 4, kPolicyScored, true>), scored_lds(env)));
+            }
+            if (env->P.rec32) ONGYM_LAUNCH_DEFRAG(true, kPolicyScored, scored_lds(env));
+            else ONGYM_LAUNCH_DEFRAG(false, kPolicyScored, scored_lds(env));
         } else if (policy >= ONGYM_POLICY_LOWEST_SPECTRUM) {
             if (env->P.rec32) ONGYM_LAUNCH_DEFRAG(true, kPolicyMisc, env->lds);
             else ONGYM_LAUNCH_DEFRAG(false, kPolicyMisc, env->lds);
@@ -985,7 +1013,12 @@ static int launch_run(ongym_env *env, int mode, int policy, int nsteps, const in
         else if (policy == ONGYM_POLICY_LOAD_BALANCING)                                                            \
             hipLaunchKernelGGL((k_run<UA, R, 4, ONGYM_POLICY_LOAD_BALANCING>), grid, block, env->lds, env->stream,  \
                                env->d_P, mode, nsteps, d_actions, d_act_out, d_flag_out, d_out, policy);                   \
-        else if (policy >= ONGYM_POLICY_LOWEST_SPECTRUM)                                                           \
+        else if (policy >= ONGYM_POLICY_LOWEST_FRAGMENTATION) {                                                    \
+            if (scored_lds(env) > 64 * 1024)                                                                       \
+                HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<UA, R, 4, kPolicyScored>), scored_lds(env))); \
+            hipLaunchKernelGGL((k_run<UA, R, 4, kPolicyScored>), grid, block, scored_lds(env), env->stream,         \
+                               env->d_P, mode, nsteps, d_actions, d_act_out, d_flag_out, d_out, policy);                   \
+        } else if (policy >= ONGYM_POLICY_LOWEST_SPECTRUM)                                                         \
             hipLaunchKernelGGL((k_run<UA, R, 4, kPolicyMisc>), grid, block, env->lds, env->stream,                  \
                                env->d_P, mode, nsteps, d_actions, d_act_out, d_flag_out, d_out, policy);                   \
         else if (env->lds <= 8192)                                                                                 \
@@ -1019,6 +1052,8 @@ int ongym_step_policy(ongym_env *env, int32_t policy, int32_t nsteps, ongym_step
         return fail_arg(env, "this policy supports at most 8 candidate routes", ONGYM_E_LIMIT);
     if (policy != ONGYM_POLICY_FIRST_FIT && env->P.n_mods_consider < env->P.n_mods)
         return fail_arg(env, "only the first-fit policy is fused for modulations_to_consider < n_mods", ONGYM_E_LIMIT);
+    if (policy == ONGYM_POLICY_MSCL && (env->P.bit_rate_mode != 0 || env->P.n_bit_rates <= 0))
+        return fail_arg(env, "the MSCL policy sums its capacity loss over the discrete bit rates: bit_rate_mode must be discrete", ONGYM_E_LIMIT);
     if (nsteps <= 0) return fail_arg(env, "nsteps must be positive");
     if (!env->has_source) { env->err = "no request source: call ongym_seed or ongym_set_requests first"; return ONGYM_E_STATE; }
     HIP_TRY(env, hipSetDevice(env->cfg.device));
@@ -1097,6 +1132,8 @@ int ongym_policy_actions(ongym_env *env, int32_t policy, int32_t *actions, uint8
         return fail_arg(env, "this policy supports at most 8 candidate routes", ONGYM_E_LIMIT);
     if (policy != ONGYM_POLICY_FIRST_FIT && env->P.n_mods_consider < env->P.n_mods)
         return fail_arg(env, "only the first-fit policy is fused for modulations_to_consider < n_mods", ONGYM_E_LIMIT);
+    if (policy == ONGYM_POLICY_MSCL && (env->P.bit_rate_mode != 0 || env->P.n_bit_rates <= 0))
+        return fail_arg(env, "the MSCL policy sums its capacity loss over the discrete bit rates: bit_rate_mode must be discrete", ONGYM_E_LIMIT);
     HIP_TRY(env, hipSetDevice(env->cfg.device));
     int rc;
     if (env->cfg.io_device) return launch_run(env, kModePolicyOnly, policy, 1, nullptr, actions, flags, nullptr);

@@ -22,6 +22,7 @@ POLICY_LOAD_BALANCING = 1
 POLICY_HIGHEST_SNR = 2
 POLICY_LOWEST_SPECTRUM, POLICY_LB_FIRST_FIT, POLICY_BEST_MOD_LB = 3, 4, 5
 POLICY_MSCL_SIMPLIFIED, POLICY_MSCL_SEQUENTIAL, POLICY_PSR, POLICY_EXACT_FIT = 6, 7, 8, 9
+POLICY_LOWEST_FRAGMENTATION, POLICY_MSCL = 10, 11
 F_BLOCKED_RESOURCES, F_BLOCKED_OSNR, F_QOT_ERROR, F_OVERFLOW, F_NO_REQUEST = 1, 2, 4, 8, 16
 
 _i32p, _f64p = C.POINTER(C.c_int32), C.POINTER(C.c_double)

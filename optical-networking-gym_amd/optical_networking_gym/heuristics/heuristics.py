@@ -178,8 +178,8 @@ def heuristic_load_balancing_first_fit_plugin(env):
     return sim_env.action_space.n - 1, True, False
 
 
-def heuristic_lowest_fragmentation(env):
-    """Reference :330-416.  Quirks kept: the request is sized slots+1 (and evaluated by the GN model at that width); the
+def heuristic_lowest_fragmentation_plugin(env):
+    """Reference :330-416, written against the plugin API (one batched GSNR launch per decision).  Quirks kept: the request is sized slots+1 (and evaluated by the GN model at that width); the
     trial allocation paints 1 (= free) over slots that are free already, so the fragmentation score (0.33*entropy +
     0.33*cuts + 0.34*rss over the ZERO-runs of the route's link rows) is one number per route; strict `<` keeps the first
     candidate of the lowest-score route whose GSNR passes."""
@@ -241,8 +241,8 @@ def _calculate_allocation_possibilities(available_slots: np.ndarray, required_sl
     return int(_window_counts(np.asarray(available_slots), int(required_slots))[-1])
 
 
-def heuristic_mscl(env):
-    """Minimum spectrum capacity loss, reference :647-749: among all (route, modulation, start) whose GSNR passes, the
+def heuristic_mscl_plugin(env):
+    """Minimum spectrum capacity loss, reference :647-749, written against the plugin API: among all (route, modulation, start) whose GSNR passes, the
     one that destroys the fewest placements — summed over the configured bit rates (at the candidate's modulation) and
     over every route of the network sharing a link with the candidate route — when its slots (no guard) are taken.
     The loss of blocking [a, b) on a row = the free windows of that width starting in (a - width, b): a difference of
@@ -506,6 +506,19 @@ heuristic_load_balancing_first_fit = _fused(_nat.POLICY_LB_FIRST_FIT, "Reference
 heuristic_mscl_simplified = _fused(_nat.POLICY_MSCL_SIMPLIFIED, "Reference :765-839, fused on device.")
 heuristic_mscl_sequential_simplified = _fused(_nat.POLICY_MSCL_SEQUENTIAL, "Reference :841-921, fused on device.")
 heuristic_exact_fit = _fused(_nat.POLICY_EXACT_FIT, "Reference :1121-1227, fused on device.")
+heuristic_lowest_fragmentation = _fused(
+    _nat.POLICY_LOWEST_FRAGMENTATION,
+    "Reference :330-414, fused on device (csrc/ongym_scored.hpp): the float score is reproduced bit for bit from a table of "
+    "p*log(p) and the reference's own summation order.")
+
+
+def heuristic_mscl(env):
+    """Reference :647-749, fused on device (csrc/ongym_scored.hpp) for discrete bit rates — the capacity loss is summed over
+    `env.bit_rates`; with continuous bit-rate selection the plugin body answers."""
+    sim_env = get_qrmsa_env(env)
+    if sim_env.bit_rate_selection != "discrete":
+        return heuristic_mscl_plugin(env)
+    return sim_env.policy_action(_nat.POLICY_MSCL)
 
 
 def heuristic_psr(env, variant: str = "O", coef_dist: float = 1.0, coef_slots: float = 1.0):

@@ -794,7 +794,143 @@ static int orc_policy_exact_fit(orc_env *e, int *bres_out, int *bosnr_out) {
     return orc_reject_action(e);
 }
 
+/* heuristic_lowest_fragmentation (:330-414), literally: every candidate start of every format of every route gets the score
+ * 0.33*mean link entropy + 0.33*cuts + 0.34*rss of the route's link rows with the trial block PAINTED 1 (quirk: 1 is "free",
+ * the block is free already, and utils.pyx:61-107 take the runs of value 0 for the "free blocks"); the request is sized
+ * slots + 1 and the GN model evaluated at that width; strict `<` keeps the first of the lowest scores. */
+static int orc_policy_lowest_fragmentation(orc_env *e, int *bres_out, int *bosnr_out) {
+    int S = e->cfg.n_slots, H = e->cfg.max_hops, bres = 0, bosnr = 0;
+    int32_t *avail = e->scratch_avail;
+    int32_t *starts = (int32_t *)malloc(sizeof(int32_t) * (size_t)(S + 1));
+    int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * (size_t)H * (size_t)S);
+    double best_score = INFINITY;
+    int best_action = -1;
+    for (int k = 0; k < e->cfg.k_paths; k++) {
+        int p = path_of(e, k);
+        if (p < 0) break;
+        int hops = e->path_hops[p];
+        for (int m = e->max_mod_idx; m >= 0; m--) {
+            int req = orc_number_slots(e, e->cur.bit_rate, m) + 1;                     /* :357 */
+            if (req <= 0) continue;
+            orc_available(e, p, avail);
+            int cnt = orc_candidates(avail, S, req, starts, S + 1);
+            if (cnt == 0) { bres = 1; continue; }
+            for (int i = 0; i < cnt; i++) {
+                int start = starts[i];
+                for (int h = 0; h < hops; h++) {                                       /* :371-372 */
+                    memcpy(tmp + (size_t)h * S, e->grid + (size_t)e->path_links[p * H + h] * S, sizeof(int32_t) * (size_t)S);
+                    for (int j = start; j < start + req && j < S; j++) tmp[(size_t)h * S + j] = 1;
+                }
+                double ent_sum = 0.0, sum_sq = 0.0, sum_len = 0.0;
+                long cuts = 0;
+                for (int h = 0; h < hops; h++) {
+                    const int32_t *row = tmp + (size_t)h * S;
+                    double entropy = 0.0;                                              /* link_shannon_entropy_, utils.pyx:61-79 */
+                    for (int j = 0; j < S;) {
+                        if (row[j] != 0) { j++; continue; }
+                        int b = j;
+                        while (j < S && row[j] == 0) j++;
+                        double pr = (double)(j - b) / (double)S;
+                        volatile double term = pr * log(pr);                          /* two roundings, as in Python */
+                        entropy += term;
+                        cuts += 1;                                                     /* fragmentation_route_cuts, :82-90 */
+                        sum_sq += (double)(j - b) * (double)(j - b);                   /* fragmentation_route_rss, :92-107 */
+                        sum_len += (double)(j - b);
+                    }
+                    entropy = entropy != 0.0 ? -entropy : 0.0;
+                    ent_sum = h == 0 ? entropy : ent_sum + entropy;                    /* sum(): 0 + e0 + e1 + ... */
+                }
+                double se = hops ? ent_sum / (double)hops : 0.0;
+                double rss = sum_len == 0.0 ? 0.0 : sqrt(sum_sq) / sum_len;
+                volatile double t1 = 0.33 * se, t2 = 0.33 * (double)cuts, t3 = 0.34 * rss;   /* no contraction */
+                volatile double t12 = t1 + t2;
+                double score = t12 + t3;
+                if (!passes(e, p, start, req, m)) { bosnr = 1; continue; }
+                if (score < best_score) { best_score = score; best_action = orc_encode_action(e, k, m, start); }
+            }
+        }
+    }
+    free(starts); free(tmp);
+    if (best_action >= 0) { *bres_out = 0; *bosnr_out = 0; return best_action; }
+    if (bosnr) bres = 0;
+    *bres_out = bres; *bosnr_out = bosnr;
+    return orc_reject_action(e);
+}
+
+/* heuristic_mscl (:647-749): among the candidates whose GSNR passes, the one that destroys the fewest placements
+ * (_calculate_allocation_possibilities, :629-645: free runs of length >= w hold len - w + 1 placements) summed over the
+ * configured bit rates at the candidate's format and over every route of the network - both directions of every pair,
+ * as the reference's dict holds them - that shares a link with the candidate route, when [start, start+n) is blocked.
+ * before - after = the free windows of width w that overlap the block = prefix-count difference (the reference recounts
+ * both rows for every candidate; same integers). */
+static int orc_policy_mscl(orc_env *e, int *bres_out, int *bosnr_out) {
+    int S = e->cfg.n_slots, H = e->cfg.max_hops, N = e->cfg.n_nodes, K = e->cfg.k_paths, NP = e->cfg.n_paths;
+    int bres = 0, bosnr = 0;
+    int32_t *avail = e->scratch_avail;
+    int32_t *starts = (int32_t *)malloc(sizeof(int32_t) * (size_t)(S + 1));
+    int32_t *rows = (int32_t *)malloc(sizeof(int32_t) * (size_t)NP * (size_t)S);      /* get_available_slots of every route */
+    int64_t *acc = (int64_t *)malloc(sizeof(int64_t) * (size_t)(S + 1));
+    for (int q = 0; q < NP; q++) orc_available(e, q, rows + (size_t)q * S);
+    int64_t best_loss = INT64_MAX;
+    int best_action = -1;
+    for (int k = 0; k < K; k++) {
+        int p = path_of(e, k);
+        if (p < 0) break;
+        for (int m = e->max_mod_idx; m >= 0; m--) {
+            int n = orc_number_slots(e, e->cur.bit_rate, m);
+            if (n <= 0) continue;
+            orc_available(e, p, avail);
+            int cnt = orc_candidates(avail, S, n, starts, S + 1);
+            if (cnt == 0) { bres = 1; continue; }
+            int64_t *loss = (int64_t *)calloc((size_t)cnt, sizeof(int64_t));
+            int have_loss = 0;
+            for (int i = 0; i < cnt; i++) {
+                int start = starts[i];
+                if (!passes(e, p, start, n, m)) { bosnr = 1; continue; }
+                if (!have_loss) {
+                    have_loss = 1;
+                    for (int b = 0; b < e->cfg.n_bit_rates; b++) {
+                        int w = orc_number_slots(e, (float)e->bit_rates[b], m);
+                        if (w <= 0) continue;
+                        memset(acc, 0, sizeof(int64_t) * (size_t)(S + 1));
+                        for (int a = 0; a < N; a++) for (int d = 0; d < N; d++) for (int kk = 0; kk < K; kk++) {
+                            int q = e->pair_paths[(a * N + d) * K + kk];
+                            if (q < 0) continue;
+                            int share = 0;
+                            for (int h = 0; h < e->path_hops[p] && !share; h++)
+                                for (int g = 0; g < e->path_hops[q] && !share; g++)
+                                    share = e->path_links[p * H + h] == e->path_links[q * H + g];
+                            if (!share) continue;
+                            const int32_t *row = rows + (size_t)q * S;
+                            int64_t c = 0;
+                            int run = 0;                    /* window [t, t+w) free <=> the free run ending at t+w-1 is >= w long */
+                            for (int j = 0; j < S; j++) {   /* acc[i] += number of free windows starting before i */
+                                run = row[j] ? run + 1 : 0;
+                                int t = j - w + 1;
+                                if (t >= 0) { if (run >= w) c++; acc[t + 1] += c; }
+                            }
+                            for (int t = S - w + 2; t <= S; t++) if (t >= 1) acc[t] += c;
+                        }
+                        for (int j = 0; j < cnt; j++) {
+                            int hi = starts[j] + n < S ? starts[j] + n : S, lo = starts[j] - w + 1 > 0 ? starts[j] - w + 1 : 0;
+                            loss[j] += acc[hi] - acc[lo];
+                        }
+                    }
+                }
+                if (loss[i] < best_loss) { best_loss = loss[i]; best_action = orc_encode_action(e, k, m, start); }
+            }
+            free(loss);
+        }
+    }
+    free(starts); free(rows); free(acc);
+    if (best_action >= 0) { *bres_out = 0; *bosnr_out = 0; return best_action; }
+    *bres_out = bres; *bosnr_out = bosnr;
+    return orc_reject_action(e);
+}
+
 int orc_policy(orc_env *e, int policy, int *bres, int *bosnr) {
+    if (policy == ONGYM_POLICY_LOWEST_FRAGMENTATION) return orc_policy_lowest_fragmentation(e, bres, bosnr);
+    if (policy == ONGYM_POLICY_MSCL) return orc_policy_mscl(e, bres, bosnr);
     if (policy == ONGYM_POLICY_LOAD_BALANCING) return orc_policy_load_balancing(e, bres, bosnr);
     if (policy == ONGYM_POLICY_HIGHEST_SNR) return orc_policy_highest_snr(e, bres, bosnr);
     if (policy == ONGYM_POLICY_LOWEST_SPECTRUM) return orc_policy_lowest_spectrum(e, bres, bosnr);
@@ -1140,6 +1276,13 @@ int orc_run_policy(orc_env *e, int policy, int nsteps, ongym_step_rec *out) {
         int a = orc_policy(e, policy, &bres, &bosnr);
         ongym_step_rec r;
         int rc = orc_step(e, a, &r);
+        if (rc == ONGYM_E_STATE && policy >= ONGYM_POLICY_LOWEST_FRAGMENTATION && (r.flags & ONGYM_F_QOT_ERROR)) {
+            /* the reference raises ValueError here (qrmsa.pyx:925-929; lowest fragmentation asked for the GN model at
+             * slots + 1): the fused loop of the product rejects the request and flags it - the checker does the same */
+            rc = orc_step(e, orc_reject_action(e), &r);
+            r.flags |= ONGYM_F_QOT_ERROR | ONGYM_F_BLOCKED_OSNR;
+            bres = bosnr = 0;
+        }
         if (rc) return rc;
         if (bres) r.flags |= ONGYM_F_BLOCKED_RESOURCES;
         if (bosnr) r.flags |= ONGYM_F_BLOCKED_OSNR;

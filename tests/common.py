@@ -58,7 +58,10 @@ def holder_for(meta: dict, batch: int = 1, capacity: int = 1024, **over) -> Conf
               frequency_start=meta["frequency_start"], frequency_slot_bandwidth=meta["slot_bw"],
               margin=meta["margin"])
     kw.update(over)
-    return ConfigHolder(golden_tables(meta["topology"]), **kw)
+    tables = golden_tables(meta["topology"])
+    if meta.get("k_paths", tables.k_paths) < tables.k_paths:     # fixtures captured with fewer candidate routes per pair
+        tables = tables.truncated(meta["k_paths"])
+    return ConfigHolder(tables, **kw)
 
 
 ALL_TRAJ = ["traj_nsfnet320", "traj_nsfnet320_hi", "traj_nobeleu320", "traj_nsfnet768", "traj_cost239",

@@ -270,10 +270,12 @@ def test_defragmentation_trajectory(tag):
 # ---- the remaining policies (heuristics.py) against decisions captured from the reference -----------------------------
 ORACLE_POLICY = {"shortest_available_path_lowest_spectrum_best_modulation": 3, "heuristic_load_balancing_first_fit": 4,
                  "best_modulation_load_balancing": 5, "heuristic_mscl_simplified": 6,
-                 "heuristic_mscl_sequential_simplified": 7, "psr_c": 8, "heuristic_exact_fit": 9}
+                 "heuristic_mscl_sequential_simplified": 7, "psr_c": 8, "heuristic_exact_fit": 9,
+                 "heuristic_lowest_fragmentation": 10, "heuristic_mscl": 11}
 
 
-@pytest.mark.parametrize("tag", ["dec_nsfnet320_a", "dec_nsfnet320_b", "dec_nsfnet320_c", "dec_cost239_d"])
+@pytest.mark.parametrize("tag", ["dec_nsfnet320_a", "dec_nsfnet320_b", "dec_nsfnet320_c", "dec_cost239_d",
+                                 "dec_nsfnet96_lf", "dec_nsfnet64_mscl"])
 def test_remaining_policies_decide_like_the_reference(tag):
     """tests/golden/dec_*.npz: at every step the reference's own heuristic functions were evaluated on the same state;
     the oracle's restatements must return the same (action, blocked_resources, blocked_osnr)."""
@@ -301,7 +303,7 @@ def test_remaining_policies_decide_like_the_reference(tag):
             assert rc == 0 and r["retry"] == d["st_retry"][row] and r["reward"] == d["st_reward"][row], row
             if not r["retry"]:
                 assert r["accepted"] == d["st_accepted"][row], row
-    assert checked == len(names) * len(d["dec_" + meta["driver"]]) >= 750
+    assert checked == len(names) * len(d["dec_" + meta["driver"]]) >= (750 if "320" in tag or "cost" in tag else 100)
 
 
 def _epreset_checks(meta, d, recs, stats_at_term, reset_counters_called_at):
