@@ -417,7 +417,8 @@ def test_bench_size_batch_65536_properties_and_sampled_oracle():
     holder = nat.ConfigHolder(tb, modulations=jocn_modulations(), num_spectrum_resources=320, batch=B, capacity=448,
                               load=300, bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), episode_length=1000,
                               auto_reset=True)
-    for r in (0, 1, 31337, B - 1):
+    rng = np.random.default_rng(7)
+    for r in [0, 1, 31337, B - 1] + [int(x) for x in rng.integers(2, B - 1, 44)]:   # 48 replicas: first/last blocks + random
         check_state_invariants(a, tb, r, 320)
         o = OracleEnv(holder, replica=r)
         o.seed(1); o.reset(); o.run_first_fit(steps)
