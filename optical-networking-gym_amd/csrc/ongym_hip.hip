@@ -938,7 +938,10 @@ static size_t field_lds(const ongym_env *env) {   // k_observe / highest-SNR k_r
     return ((env->lds + ((size_t)2 * P.n_slots + 2) * (sizeof(double) + 2 + 1) + kMaxMods * kMaxRowWords * 8) + 15) & ~(size_t)15;
 }
 
-static size_t scored_lds(const ongym_env *env) { return ((env->lds + 15) & ~(size_t)15) + scored_lds_bytes(env->P.row_words); }
+// lowest fragmentation needs no scratch; MSCL the block of scored_lds_bytes
+static size_t scored_lds(const ongym_env *env, int policy) {
+    return policy == ONGYM_POLICY_MSCL ? ((env->lds + 15) & ~(size_t)15) + scored_lds_bytes(env->P.row_words) : env->lds;
+}
 
 static int launch_run(ongym_env *env, int mode, int policy, int nsteps, const int32_t *d_actions, int32_t *d_act_out,
                       uint8_t *d_flag_out, ongym_step_rec *d_out) {
@@ -986,12 +989,12 @@ static int launch_run(ongym_env *env, int mode, int policy, int nsteps, const in
             if (env->P.rec32) ONGYM_LAUNCH_DEFRAG(true, ONGYM_POLICY_LOAD_BALANCING, env->lds);
             else ONGYM_LAUNCH_DEFRAG(false, ONGYM_POLICY_LOAD_BALANCING, env->lds);
         } else if (policy >= ONGYM_POLICY_LOWEST_FRAGMENTATION) {
-            if (scored_lds(env) > 64 * 1024) {
-                HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<true, true, 4, kPolicyScored, true>), scored_lds(env)));
-                HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<true, false, 4, kPolicyScored, true>), scored_lds(env)));
+            if (scored_lds(env, policy) > 64 * 1024) {
+                HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<true, true, 4, kPolicyScored, true>), scored_lds(env, policy)));
+                HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<true, false, 4, kPolicyScored, true>), scored_lds(env, policy)));
             }
-            if (env->P.rec32) ONGYM_LAUNCH_DEFRAG(true, kPolicyScored, scored_lds(env));
-            else ONGYM_LAUNCH_DEFRAG(false, kPolicyScored, scored_lds(env));
+            if (env->P.rec32) ONGYM_LAUNCH_DEFRAG(true, kPolicyScored, scored_lds(env, policy));
+            else ONGYM_LAUNCH_DEFRAG(false, kPolicyScored, scored_lds(env, policy));
         } else if (policy >= ONGYM_POLICY_LOWEST_SPECTRUM) {
             if (env->P.rec32) ONGYM_LAUNCH_DEFRAG(true, kPolicyMisc, env->lds);
             else ONGYM_LAUNCH_DEFRAG(false, kPolicyMisc, env->lds);
@@ -1014,9 +1017,9 @@ static int launch_run(ongym_env *env, int mode, int policy, int nsteps, const in
             hipLaunchKernelGGL((k_run<UA, R, 4, ONGYM_POLICY_LOAD_BALANCING>), grid, block, env->lds, env->stream,  \
                                env->d_P, mode, nsteps, d_actions, d_act_out, d_flag_out, d_out, policy);                   \
         else if (policy >= ONGYM_POLICY_LOWEST_FRAGMENTATION) {                                                    \
-            if (scored_lds(env) > 64 * 1024)                                                                       \
-                HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<UA, R, 4, kPolicyScored>), scored_lds(env))); \
-            hipLaunchKernelGGL((k_run<UA, R, 4, kPolicyScored>), grid, block, scored_lds(env), env->stream,         \
+            if (scored_lds(env, policy) > 64 * 1024)                                                                       \
+                HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<UA, R, 4, kPolicyScored>), scored_lds(env, policy))); \
+            hipLaunchKernelGGL((k_run<UA, R, 4, kPolicyScored>), grid, block, scored_lds(env, policy), env->stream,         \
                                env->d_P, mode, nsteps, d_actions, d_act_out, d_flag_out, d_out, policy);                   \
         } else if (policy >= ONGYM_POLICY_LOWEST_SPECTRUM)                                                         \
             hipLaunchKernelGGL((k_run<UA, R, 4, kPolicyMisc>), grid, block, env->lds, env->stream,                  \

@@ -19,8 +19,13 @@ namespace ongym {
 
 constexpr int kPolicyScored = ONGYM_POLICY_LOWEST_FRAGMENTATION;   // template value of the shared instantiation
 
-// extra dynamic LDS of the kPolicyScored instantiation: H, LOSS int32[64*W] and PH int32[64*W + 1] (capacity-loss search)
-__host__ __device__ inline size_t scored_lds_bytes(int row_words) { return ((size_t)(3 * 64 * row_words + 1) * 4 + 15) & ~(size_t)15; }
+// extra dynamic LDS of the kPolicyScored instantiation (capacity-loss search of MSCL):
+//   OKB u64[8][16] | LOSSM int32[8][64*W] | PH int32[64*W + 1 (+1 pad)] | H int32[kScoredWidths][64*W]
+constexpr int kScoredWidths = 12;      // window widths whose route counts are accumulated in one pass over the routes
+__host__ __device__ inline size_t scored_lds_bytes(int row_words) {
+    return (size_t)kMaxMods * kMaxRowWords * 8 + (size_t)kMaxMods * 64 * row_words * 4 + ((size_t)64 * row_words + 2) * 4 +
+           (size_t)kScoredWidths * 64 * row_words * 4 + 16;
+}
 
 // Quirk kept (documented in heuristics.py of this package): the trial allocation paints 1 over slots that are 1 already, so
 // the score depends on the route only; the "free blocks" of utils.pyx:61-107 are the runs of value 0 = OCCUPIED slots.
@@ -90,7 +95,7 @@ __device__ __forceinline__ long long wave_min_i64(long long v) {
     return v;
 }
 
-// scr: H int32[64*W] | LOSS int32[64*W] | PH int32[64*W + 1]
+// scr: the block described at scored_lds_bytes (16-byte aligned)
 template <bool UNIFORM_ALPHA, bool R32>
 __device__ __forceinline__ void policy_scored(Ctx &c, int policy, int src, int dst, double margin, Choice &ch, int32_t *scr) {
     const Params &P = c.P;
@@ -100,7 +105,10 @@ __device__ __forceinline__ void policy_scored(Ctx &c, int policy, int src, int d
     int bres = 0, bosnr = 0;
     double best_score = INFINITY;
     long long best_loss = 0x7fffffffffffffffll;
-    int32_t *H = scr, *LOSS = scr + 64 * RW, *PH = scr + 128 * RW;
+    uint64_t *OKB = reinterpret_cast<uint64_t *>(scr);
+    int32_t *LOSSM = scr + kMaxMods * kMaxRowWords * 2;
+    int32_t *PH = LOSSM + kMaxMods * 64 * RW;
+    int32_t *H = PH + 64 * RW + 2;
     auto take = [&](int k, int m, int slot, int n, const PathRef &p) {
         ch.action = k * M * S + (max_mod - m) * S + slot;          // get_action_index, heuristics.py:36-54
         ch.route = k; ch.mod = m; ch.slot = slot; ch.n = n; ch.hops = p.hops; ch.mylink = p.mylink;
@@ -141,69 +149,157 @@ __device__ __forceinline__ void policy_scored(Ctx &c, int policy, int src, int d
             continue;
         }
         // ---- heuristic_mscl ------------------------------------------------------------------------------------------
+        // 1. the GN model for every candidate start of every format: OKB[m] = the starts whose GSNR passes
+        bool any_ok = false;
         for (int m = max_mod; m >= 0; m--) {
+            if (c.lane < kMaxRowWords) OKB[m * kMaxRowWords + c.lane] = 0ull;
             const int n = uniform_i32(c.nreq[m]);
             if (n <= 0) continue;
             int rr = 1;
             uint64_t v = run_and(free_ext, rr, n + 1);
             if (!any_bits(v)) { bres = 1; continue; }
-            uint64_t okb = 0;                                      // starts whose GSNR passes (lane-distributed like v)
+            uint64_t okb = 0;                                      // lane-distributed like v
             for (;;) {
                 const int s0 = first_set(v);
                 if (s0 < 0) break;
                 if (c.lane == (s0 >> 6)) v &= ~(1ull << (s0 & 63));
+                if (UNIFORM_ALPHA && P.ase_shortcut) {
+                    // exact lower bound (see policy_first_fit): ASE + self-channel term alone already above the limit. It
+                    // only grows with the slot index, so every later start of this format fails too
+                    const double bw = P.slot_bw * n, fc = P.f0 + (P.slot_bw * s0) + (P.slot_bw * (n / 2.0));
+                    const double lb = (bw * fc * p.ase) * c.rp[0] + c.nlic[m] * (p.w1 * c.selfa[m]);
+                    if (uniform_i32(lb >= c.lim[m] * (1.0 + 1e-9))) { bosnr = 1; c.gn_skips++; break; }
+                }
                 if (L < 0) L = gn_build_list<R32>(c, p.m0, p.m1);
                 const GnLin g = gn_eval<UNIFORM_ALPHA, R32>(c, p, L, s0, n, coef_for_mod(c, m));
                 if (qot_ok(c, g, m, margin)) { if (c.lane == (s0 >> 6)) okb |= 1ull << (s0 & 63); }
                 else bosnr = 1;
             }
-            if (!any_bits(okb)) continue;
-            // capacity loss of taking [start, start+n) (no guard, :719-720): per configured bit rate (width w at THIS format)
-            // and per route q of the network sharing a link with the candidate route, the free windows of width w of q's
-            // row that overlap the block, i.e. the window starts t in (start - w, start + n). H[t] = number of routes with
-            // a free window at t; PH its prefix sum; LOSS[start] += PH[min(start+n, S)] - PH[max(0, start-w+1)].
-            // (The reference's route list holds every route twice, once per direction: a uniform factor 2 on every loss.)
-            for (int j = 0; j < RW; j++) LOSS[64 * j + c.lane] = 0;
+            if (c.lane < kMaxRowWords) OKB[m * kMaxRowWords + c.lane] = okb;
+            if (any_bits(okb)) {
+                any_ok = true;
+                for (int j = 0; j < RW; j++) LOSSM[m * 64 * RW + 64 * j + c.lane] = 0;
+            }
+        }
+        wave_sync();
+        STAMPW(c, 1);
+        if (!any_ok) continue;
+        // 2. capacity loss of taking [start, start+n) (no guard, :719-720): per configured bit rate (width w at the candidate's
+        //    format) and per route q of the network sharing a link with the candidate route, the free windows of width w of
+        //    q's row that overlap the block, i.e. the window starts t in (start - w, start + n).  H_w[t] = number of such
+        //    routes with a free window of width w at t; PH_w its prefix sum;
+        //        LOSS[m][start] = sum over bit rates of PH_w[min(start+n, S)] - PH_w[max(0, start-w+1)],  w = slots(bit rate, m).
+        //    The distinct widths of all (format, bit rate) pairs (a bitmap WB, word per lane) are served by ONE pass over the
+        //    routes: a route's row is loaded once and the run-AND ladder extended width by width (ascending).
+        //    (The reference's route list holds every route twice, once per direction: a uniform factor 2 on every loss.)
+        uint64_t WB = 0;
+        for (int m = max_mod; m >= 0; m--) {
+            if (!any_bits(c.lane < kMaxRowWords ? OKB[m * kMaxRowWords + c.lane] : 0ull)) continue;
             for (int b = 0; b < P.n_bit_rates; b++) {
                 const int w = uniform_i32(G(P.nreq_tab)[b * kMaxMods + m]);
-                if (w <= 0) continue;
-                for (int j = 0; j < RW; j++) H[64 * j + c.lane] = 0;
-                for (int q = 0; q < P.n_paths; q++) {
-                    const uint64_t q0 = G(P.path_mask)[2 * q], q1 = G(P.path_mask)[2 * q + 1];
-                    if (!uniform_i32(((q0 & p.m0) | (q1 & p.m1)) != 0)) continue;
-                    const PathRef pq = load_path(c, q);
-                    int r2 = 1;
-                    const uint64_t Wq = run_and(row_of(path_free_ext(c, pq)), r2, w);
-                    for (int j = 0; j < RW; j++) {
-                        const uint64_t word = readlane_u64(Wq, j);
-                        H[64 * j + c.lane] += (int32_t)((word >> c.lane) & 1ull);
-                    }
-                }
-                int carry = 0;
-                if (c.lane == 0) PH[0] = 0;
-                for (int j = 0; j < RW; j++) {
-                    const int incl = wave_incl_scan_i32(H[64 * j + c.lane], c.lane);
-                    PH[64 * j + c.lane + 1] = carry + incl;
-                    carry += __builtin_amdgcn_readlane(incl, 63);
-                }
-                wave_sync();
-                for (int j = 0; j < RW; j++) {
-                    const int t = 64 * j + c.lane;
-                    if (t < S) LOSS[t] += PH[min(t + n, S)] - PH[max(0, t - w + 1)];
-                }
-                wave_sync();
+                if (w > 0 && w <= S && c.lane == (w >> 6)) WB |= 1ull << (w & 63);   // wider than the row: no window anywhere
             }
+        }
+        auto rank_of = [&](int w) {      // index of width w among the set bits of WB (ascending)
+            int below = c.lane < (w >> 6) ? __popcll((unsigned long long)WB)
+                      : c.lane == (w >> 6) ? __popcll((unsigned long long)(WB & ((1ull << (w & 63)) - 1ull))) : 0;
+#pragma unroll
+            for (int mm = 8; mm >= 1; mm >>= 1) below += __shfl_xor(below, mm);      // words live in lanes 0..15
+            return uniform_i32(below);
+        };
+        int D = c.lane < kMaxRowWords ? __popcll((unsigned long long)WB) : 0;
+#pragma unroll
+        for (int mm = 8; mm >= 1; mm >>= 1) D += __shfl_xor(D, mm);
+        D = uniform_i32(D);
+        for (int i0 = 0; i0 < D; i0 += kScoredWidths) {            // kScoredWidths widths of the ascending list per pass
+            const int nw = min(D - i0, kScoredWidths);
+            for (int i = c.lane; i < nw * 64 * RW; i += kWave) H[i] = 0;
+            wave_sync();
+            STAMPW(c, 2);
+            // the widths of this pass, ascending: lane i keeps the i-th
+            int wv = 0;
+            {
+                uint64_t WBp = WB;
+                for (int i = 0; i < i0 + nw; i++) {
+                    const int w = first_set(WBp);
+                    if (c.lane == (w >> 6)) WBp &= ~(1ull << (w & 63));
+                    if (c.lane == i - i0) wv = w;
+                }
+            }
+            for (int cbase = 0; cbase < P.n_paths; cbase += kWave) {            // 64 routes of the network per ballot
+                const int t = cbase + c.lane;
+                bool touch = false;
+                if (t < P.n_paths) touch = ((G(P.path_mask)[2 * t] & p.m0) | (G(P.path_mask)[2 * t + 1] & p.m1)) != 0;
+                uint64_t bal = __ballot(touch);
+                if (!bal) continue;
+                int q = cbase + __ffsll((unsigned long long)bal) - 1;
+                bal &= bal - 1;
+                PathRef pq = load_path(c, q);
+                for (;;) {
+                    const bool more = bal != 0;
+                    const int qn = more ? cbase + __ffsll((unsigned long long)bal) - 1 : q;
+                    bal &= bal - 1;
+                    const PathRef pn = load_path(c, qn);                          // in flight while this route is processed
+                    uint64_t x = row_of(path_free_ext(c, pq));
+                    int r2 = 1;
+                    for (int i = 0; i < nw; i++) {
+                        const int w = __builtin_amdgcn_readlane(wv, i);
+                        x = run_and(x, r2, w);
+                        int32_t *Hi = H + i * 64 * RW;
+                        for (int j = 0; j < RW; j++) {                            // ds_add_u32 without return: no round trip
+                            const uint64_t word = readlane_u64(x, j);
+                            if (word) __hip_atomic_fetch_add(&Hi[64 * j + c.lane], (int32_t)((word >> c.lane) & 1ull),
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        }
+                    }
+                    if (!more) break;
+                    q = qn; pq = pn;
+                }
+            }
+            wave_sync();
+            STAMPW(c, 3);
+            for (int m = max_mod; m >= 0; m--) {
+                if (!any_bits(c.lane < kMaxRowWords ? OKB[m * kMaxRowWords + c.lane] : 0ull)) continue;
+                const int n = uniform_i32(c.nreq[m]);
+                for (int b = 0; b < P.n_bit_rates; b++) {
+                    const int w = uniform_i32(G(P.nreq_tab)[b * kMaxMods + m]);
+                    if (w <= 0 || w > S) continue;
+                    const int i = rank_of(w) - i0;
+                    if (i < 0 || i >= nw) continue;
+                    const int32_t *Hi = H + i * 64 * RW;
+                    int carry = 0;
+                    if (c.lane == 0) PH[0] = 0;
+                    for (int j = 0; j < RW; j++) {
+                        const int incl = wave_incl_scan_i32((int)Hi[64 * j + c.lane], c.lane);
+                        PH[64 * j + c.lane + 1] = carry + incl;
+                        carry += __builtin_amdgcn_readlane(incl, 63);
+                    }
+                    wave_sync();
+                    for (int j = 0; j < RW; j++) {
+                        const int t = 64 * j + c.lane;
+                        if (t < S) LOSSM[m * 64 * RW + t] += PH[min(t + n, S)] - PH[max(0, t - w + 1)];
+                    }
+                    wave_sync();
+                }
+            }
+        }
+        STAMPW(c, 4);
+        // 3. the passing start of least loss, formats high to low, strict `<`: the first of the minima in the reference's order
+        for (int m = max_mod; m >= 0; m--) {
+            const uint64_t okb = c.lane < kMaxRowWords ? OKB[m * kMaxRowWords + c.lane] : 0ull;
+            if (!any_bits(okb)) continue;
             long long key = 0x7fffffffffffffffll;
             for (int j = 0; j < RW; j++) {
                 const uint64_t word = readlane_u64(okb, j);
                 const int t = 64 * j + c.lane;
-                if ((word >> c.lane) & 1ull) { const long long kk = ((long long)LOSS[t] << 16) | t; key = kk < key ? kk : key; }
+                if ((word >> c.lane) & 1ull) { const long long kk = ((long long)LOSSM[m * 64 * RW + t] << 16) | t; key = kk < key ? kk : key; }
             }
             key = wave_min_i64(key);
             const long long loss = key >> 16;
-            if (loss < best_loss) { best_loss = loss; take(k, m, (int)(key & 0xFFFF), n, p); }   // strict <: first of the minima
-            wave_sync();
+            if (loss < best_loss) { best_loss = loss; take(k, m, (int)(key & 0xFFFF), uniform_i32(c.nreq[m]), p); }
         }
+        wave_sync();
+        STAMPW(c, 5);
     }
     if (ch.route >= 0) return;                                     // (action, False, False)
     if (policy == ONGYM_POLICY_LOWEST_FRAGMENTATION && bosnr) bres = 0;
