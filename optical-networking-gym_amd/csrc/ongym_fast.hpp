@@ -720,41 +720,6 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         FSTAMP(10);
         pop_request();
         FSTAMP(7);
-#ifdef ONGYM_X_SCAN1
-        for (int ch = ((active + kWave - 1) / kWave) - 1; ch >= 0; ch--) {
-            const float r = rr[ch * kWave + lane];                          // unused entries hold +inf
-            uint64_t bal = __ballot(r <= v_at);
-            FSTAMP(8);
-            while (bal) {
-                const int ln = 63 - __builtin_clzll(bal);                   // highest index first: the hole is filled by a keeper
-                bal &= ~(1ull << ln);
-                const int idx = ch * kWave + ln;
-                const uint2 ab = rec[idx + vz];                             // same address in every lane: broadcast read
-                const uint32_t nk = ((ab.y >> 14) & 0x1FFu) + 1u, sk = ((ab.y & 0x7FFu) - nk) >> 1;
-                const uint32_t hi = min(sk + nk + 1u, (uint32_t)S);         // frees n+1 slots, clamped at S (quirk Q7)
-                if (__builtin_amdgcn_readfirstlane(nk) <= 32u)
-                    mark_v(ab.x, M64 ? (a2[idx + vz] & 0xFFFFFu) : 0u, sk, hi - sk, true);
-                else {
-                    uint64_t mask = __builtin_amdgcn_readfirstlane(ab.x);
-                    if (M64) mask |= (uint64_t)(__builtin_amdgcn_readfirstlane(a2[idx]) & 0xFFFFFu) << 32;
-                    mark(mask, (int)__builtin_amdgcn_readfirstlane(sk), (int)__builtin_amdgcn_readfirstlane(hi), true);
-                }
-                const int last = active - 1;
-                // move the last record into the hole, neutralise the vacated entry
-                const uint2 lab = rec[last];
-                const float lr = rr[last];
-                if (idx != last) {
-                    lds_write_lane0(rec_base + (uint32_t)idx * 8u, (uint64_t)lab.x | ((uint64_t)lab.y << 32), rr_base + (uint32_t)idx * 4u, __float_as_uint(lr));
-                    if (M64) lds_write_lane0_b32(a2_base + (uint32_t)idx * 4u, a2[last]);
-                }
-                lds_write_lane0(rec_base + (uint32_t)last * 8u, 0ull, rr_base + (uint32_t)last * 4u, 0x7F800000u);
-                if (M64) lds_write_lane0_b32(a2_base + (uint32_t)last * 4u, 0u);
-                active = last;
-                wave_sync();
-                FSTAMP(9);
-            }
-        }
-#else
         // Departures: release times of 4 chunks of 64 records are read together (one LDS round trip), highest chunk first.
         // Processing a chunk only rewrites entries at or above the hole being filled, so the comparisons made ahead of time
         // for the lower chunks stay valid.
@@ -800,7 +765,6 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             if (b2) depart(top - 2, b2);
             if (b3) depart(top - 3, b3);
         }
-#endif
         d_active_sum += (unsigned long long)active;
         const bool terminated = epp == P.episode_length;
         if (terminated) d_episodes++;
