@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Soak: 1 024 replicas x 8 000 steps (eight episodes) per topology with launch power -8..+8 dBm, load 100..1000 Erlang and
 margins 0..3 dB spread over the replicas; every replica's final grid, clocks and counters against the CPU oracle
-(OpenMP over replicas, ~1 min).  Last run (round 1): 0 differing replicas of 1 024 on NSFNET and on COST239, i.e.
-16.4 M requests without one differing accept / slot decision.   python tools/soak_vs_oracle.py   (repository root, GPU)"""
+(OpenMP over replicas, ~1 min).  Last run (round 2, lean kernel, profiles/r02_soak_vs_oracle.txt): 0 differing replicas of 1 024 on NSFNET and on COST239,
+i.e. 16.4 M requests without one differing accept / slot decision.   python tools/soak_vs_oracle.py   (repository root, GPU)"""
 import sys, os, time
 sys.path[:0] = ["tests", "optical-networking-gym_amd"]
 import numpy as np
