@@ -39,8 +39,7 @@ enum {
 enum {
     ONGYM_POLICY_FIRST_FIT = 0,      /* heuristic_shortest_available_path_first_fit_best_modulation, heuristics.py:923-966 */
     ONGYM_POLICY_LOAD_BALANCING = 1, /* load_balancing_best_modulation, heuristics.py:547-627 (graph_load.py heuristic 4) */
-    ONGYM_POLICY_HIGHEST_SNR = 2,    /* heuristic_highest_snr, heuristics.py:272-328 (graph_load.py heuristic 2); needs
-                                        uniform attenuation */
+    ONGYM_POLICY_HIGHEST_SNR = 2,    /* heuristic_highest_snr, heuristics.py:272-328 (graph_load.py heuristic 2) */
     /* the cheaper remaining policies of heuristics.py, one shared kernel instantiation (graph_launch_power.py 2,3,6,7,9): */
     ONGYM_POLICY_LOWEST_SPECTRUM = 3, /* shortest_available_path_lowest_spectrum_best_modulation, :431-490 */
     ONGYM_POLICY_LB_FIRST_FIT = 4,    /* heuristic_load_balancing_first_fit, :202-269 */
@@ -262,7 +261,8 @@ int ongym_policy_actions(ongym_env *env, int32_t policy, int32_t *actions, uint8
  * mask uint8   [batch][k_paths*Mc*n_slots + 1]            (info['mask'], last entry = reject = 1)
  * Mc = cfg.n_mods_consider.  For Mc < n_mods the call first sets ongym_stats.max_modulation_idx like
  * get_max_modulation_index (qrmsa.pyx:543-581) and describes the Mc formats at and below it.
- * Needs uniform attenuation and slot_bandwidth == channel_width*1e9. */
+ * Needs slot_bandwidth == channel_width*1e9 (the reference's observation mixes the two, core/osnr.pyx:259-369). With per-link
+ * attenuation the interferer field is evaluated term by term (no pair table): same results, about ten times slower. */
 int ongym_observe(ongym_env *env, float *obs, uint8_t *mask);
 
 /* Plugin-API queries on one replica (host buffers always): */

@@ -1551,6 +1551,15 @@ __device__ __forceinline__ void field_tile(const Params &P, int lane, double *Fx
     }
 }
 
+// self-channel term of a candidate of n slots on a path: sum over its links of w1_l * asinh(pi^2 |b2| B^2 / (4 alpha_l))
+// (core/osnr.pyx:58-61); one table product when the attenuation is uniform
+__device__ __forceinline__ double path_self_term(const Ctx &c, const PathRef &p, int n) {
+    const Params &P = c.P;
+    if (P.uniform_alpha) return G(P.path_w1)[p.id] * G(P.self_asinh)[n];
+    const double bw = P.slot_bw * n;
+    return wave_sum(c.lane < p.hops ? c.lw[2 * p.mylink] * asinh(c.lsc[p.mylink] * (bw * bw)) : 0.0);
+}
+
 template <bool R32>
 __device__ __forceinline__ void build_field(Ctx &c, const PathRef &p, uint64_t free_ext, const FieldLds &fl) {
     const Params &P = c.P;
@@ -1604,6 +1613,8 @@ __device__ __forceinline__ void build_field(Ctx &c, const PathRef &p, uint64_t f
         const int j = base + c.lane;
         int c2k = 0, nk = 0;
         double w1 = 0.0, pw2 = 0.0;
+        uint64_t km0 = 0, km1 = 0;      // shared links of interferer j (kept for the per-link attenuation form)
+        double kphi = 0.0;
         if (j < L) {
             const int idx = c.list[j];
             const uint32_t a = c.sa[idx], b = c.sb[idx];
@@ -1613,12 +1624,43 @@ __device__ __forceinline__ void build_field(Ctx &c, const PathRef &p, uint64_t f
             uint64_t m0, m1;
             if (R32) { m0 = a & (uint32_t)p.m0; m1 = 0; }
             else { int pk = a & 0xFFFF; m0 = G(P.path_mask)[2 * pk] & p.m0; m1 = G(P.path_mask)[2 * pk + 1] & p.m1; }
+            km0 = m0; km1 = m1; kphi = c.phi[rec_mod<R32>(a, b)];
             double w2 = 0.0;
             while (m0) { int l = __ffsll((unsigned long long)m0) - 1; m0 &= m0 - 1; w1 += c.lw[2 * (l)]; w2 += c.lw[2 * (l) + 1]; }
             while (m1) { int l = 64 + __ffsll((unsigned long long)m1) - 1; m1 &= m1 - 1; w1 += c.lw[2 * (l)]; w2 += c.lw[2 * (l) + 1]; }
             pw2 = c.phi[rec_mod<R32>(a, b)] * w2;
         }
         const int tile_n = min(kWave, L - base);
+        if (!P.uniform_alpha) {
+            // per-link attenuation: the asinh difference depends on the link (core/osnr.pyx:68-84), no table and no summed
+            // weights - every (centre, interferer, shared link) term is evaluated like gn_eval's generic branch does
+            for (int x0 = 0; x0 < nxl; x0 += kWave) {
+                const bool live = x0 + c.lane < nxl;
+                const int x = live ? xlist[x0 + c.lane] : 0;
+                double f = 0.0;
+                for (int t = 0; t < tile_n; t++) {
+                    const int cc = __builtin_amdgcn_readlane(c2k, t), nn = __builtin_amdgcn_readlane(nk, t);
+                    uint64_t m0 = readlane_u64(km0, t), m1 = readlane_u64(km1, t);
+                    const double ph = readlane_f64(kphi, t);
+                    const int adi = abs(x - cc);
+                    const bool on = adi > nn;              // |df| > Bk/2; centres overlapping the interferer are never needed
+                    const double bk = P.slot_bw * nn, adf = (0.5 * P.slot_bw) * (double)(on ? adi : nn + 1);
+                    const double hi = adf + 0.5 * bk, lo = adf - 0.5 * bk, corr = ph * (bk / adf);
+                    double ft = 0.0;
+                    while (m0 | m1) {
+                        int l;
+                        if (m0) { l = __ffsll((unsigned long long)m0) - 1; m0 &= m0 - 1; }
+                        else { l = 64 + __ffsll((unsigned long long)m1) - 1; m1 &= m1 - 1; }
+                        const double ck = c.lcl[l] * bk;
+                        ft += asinh_diff(ck * hi, ck * lo) * c.lw[2 * l] - corr * c.lw[2 * l + 1];
+                    }
+                    if (on) f += ft;
+                }
+                if (live) Fx[x] += f;
+            }
+            STAMPW(c, 7);
+            continue;
+        }
         // all interferers of the tile inside the pair table? (always, unless a replayed trace carries a bit rate
         // beyond the configured ones) -> branch-free inner loop with 4 gathers in flight
         const bool all_tab = __ballot(j < L && nk > P.tab_nmax) == 0;
@@ -1713,13 +1755,13 @@ __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, ui
             PathRef p = load_path(c, path);
             const uint64_t free_ext = path_free_ext(c, p);
             build_field<R32>(c, p, free_ext, FieldLds{Fx, Vw, xlist, needx});
-            const double pw1 = G(P.path_w1)[path], pase = G(P.path_ase)[path];
+            const double pase = G(P.path_ase)[path];
             for (int mi = 0; mi < Mall && !found; mi++) {
                 const int m = Mall - 1 - mi;
                 const int n = uniform_i32(c.nreq[m]);
                 if (n <= 0 || n > S) continue;
                 const double bw = P.slot_bw * n, lim = c.lim[m];
-                const double self = pw1 * G(P.self_asinh)[n], nlic = G(P.nli_coef)[n] * c.rp[1];
+                const double self = path_self_term(c, p, n), nlic = G(P.nli_coef)[n] * c.rp[1];
                 bool pass = false;
                 for (int i = 0; i < W; i++) {
                     const uint64_t w = Vw[mi * kMaxRowWords + i];
@@ -1773,7 +1815,7 @@ __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, ui
         STAMPW(c, 9);
         // ---- per format of the window, best first (mod_list = reversed(modulations[start : start + M]), :716-717); the field
         // builder numbers its valid-start rows from the best of ALL formats: row fi = n_mods - 1 - m
-        const double pw1 = G(P.path_w1)[path], pase = G(P.path_ase)[path];
+        const double pase = G(P.path_ase)[path];
         // features that depend on the path only (:632-652, 660-663)
         const double Sd = (double)S, S1 = (double)(S - 1), inv_S = 1.0 / Sd, inv_S1 = 1.0 / S1;
         double mb = 0.0, sb = 0.0;
@@ -1794,7 +1836,7 @@ __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, ui
                 continue;
             }
             const double thr = P.mod_thr[m], bw = P.slot_bw * n, inv_thr = 1.0 / fabs(thr);
-            const double self = pw1 * G(P.self_asinh)[n], nlic = G(P.nli_coef)[n] * c.rp[1];
+            const double self = path_self_term(c, p, n), nlic = G(P.nli_coef)[n] * c.rp[1];
             // the valid starts of _get_candidates (:590), compacted: ascending slot indices in xlist (free again after the
             // field was built), so that the per-candidate arithmetic runs on dense lanes
             int cnt = 0;
@@ -1859,7 +1901,7 @@ __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, ui
 // Every valid start of every (path, modulation) pair is evaluated (one LDS read of the path's interferer field per
 // candidate); among those that clear threshold + margin the highest GSNR wins, first one in (path, modulation best
 // first, slot ascending) order on ties — the reference's strict `osnr > best_osnr`.
-template <bool R32>
+template <bool UNIFORM_ALPHA, bool R32>
 __device__ __forceinline__ void policy_highest_snr(Ctx &c, int src, int dst, double launch_power, double margin, Choice &ch) {
     const Params &P = c.P;
     const int M = P.n_mods, S = P.n_slots, max_mod = M - 1, W = P.row_words;
@@ -1876,13 +1918,13 @@ __device__ __forceinline__ void policy_highest_snr(Ctx &c, int src, int dst, dou
         c.paths_tried++; c.path_hops += p.hops;
         const uint64_t free_ext = path_free_ext(c, p);
         build_field<R32>(c, p, free_ext, c.fl);
-        const double pw1 = G(P.path_w1)[path], pase = G(P.path_ase)[path];
+        const double pase = G(P.path_ase)[path];
         for (int m = max_mod; m >= 0; m--) {
             const int mi = max_mod - m;
             const int n = uniform_i32(c.nreq[m]);
             if (n <= 0) continue;
             const double thr = P.mod_thr[m] + margin, lim = c.lim[m], bw = P.slot_bw * n;
-            const double self = pw1 * G(P.self_asinh)[n], nlic = G(P.nli_coef)[n] * c.rp[1];
+            const double self = path_self_term(c, p, n), nlic = G(P.nli_coef)[n] * c.rp[1];
             int nvalid = 0;
             for (int i = 0; i < W; i++) {
                 const uint64_t w = c.fl.Vw[mi * kMaxRowWords + i];
@@ -1925,7 +1967,7 @@ __device__ __forceinline__ void policy_highest_snr(Ctx &c, int src, int dst, dou
     ch.hops = p.hops; ch.mylink = p.mylink; ch.m0 = p.m0;
     ch.action = ch.route * M * S + (max_mod - ch.mod) * S + ch.slot;
     const int L = gn_build_list<R32>(c, p.m0, p.m1);
-    GnLin g = gn_eval<true, R32>(c, p, L, ch.slot, ch.n);
+    GnLin g = gn_eval<UNIFORM_ALPHA, R32>(c, p, L, ch.slot, ch.n);
     c.gn_evals--;   // not a candidate evaluation of the heuristic
     ch.g.ase = uniform_f64(g.ase); ch.g.nli = uniform_f64(g.nli);
     (void)launch_power;

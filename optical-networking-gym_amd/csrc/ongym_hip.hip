@@ -71,7 +71,7 @@ __global__ __launch_bounds__(64, WAVES) void k_run(const Params *__restrict__ Pp
         if (mode == kModeActionStep) {
             outcome = evaluate_action<UA, R32>(c, src, dst, lp, mg, actions[c.replica], ch);
         } else {
-            if (POLICY == ONGYM_POLICY_HIGHEST_SNR) policy_highest_snr<R32>(c, src, dst, lp, mg, ch);
+            if (POLICY == ONGYM_POLICY_HIGHEST_SNR) policy_highest_snr<UA, R32>(c, src, dst, lp, mg, ch);
             else if (POLICY == ONGYM_POLICY_LOAD_BALANCING) policy_load_balancing<UA, R32>(c, src, dst, lp, mg, ch);
             else if (POLICY == kPolicyMisc) policy_misc<UA, R32>(c, policy_id, src, dst, mg, ch);
             else if (POLICY == kPolicyScored)
@@ -967,12 +967,11 @@ static int launch_run(ongym_env *env, int mode, int policy, int nsteps, const in
         env->timed = true;
         return 0;
     }
-    if (policy == ONGYM_POLICY_HIGHEST_SNR) {
-        if (!env->P.uniform_alpha) return fail_arg(env, "the highest-SNR policy needs uniform attenuation", ONGYM_E_LIMIT);
-        if (field_lds(env) > 64 * 1024) {
-            HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<true, true, 4, ONGYM_POLICY_HIGHEST_SNR>), field_lds(env)));
-            HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<true, false, 4, ONGYM_POLICY_HIGHEST_SNR>), field_lds(env)));
-        }
+    if (policy == ONGYM_POLICY_HIGHEST_SNR && field_lds(env) > 64 * 1024) {
+        HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<true, true, 4, ONGYM_POLICY_HIGHEST_SNR>), field_lds(env)));
+        HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<true, false, 4, ONGYM_POLICY_HIGHEST_SNR>), field_lds(env)));
+        HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<false, true, 4, ONGYM_POLICY_HIGHEST_SNR>), field_lds(env)));
+        HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<false, false, 4, ONGYM_POLICY_HIGHEST_SNR>), field_lds(env)));
     }
 #define ONGYM_LAUNCH_DEFRAG(R, POL, LDS)                                                                           \
     hipLaunchKernelGGL((k_run<true, R, 4, POL, true>), grid, block, LDS, env->stream, env->d_P, mode, nsteps,      \
@@ -1011,7 +1010,7 @@ static int launch_run(ongym_env *env, int mode, int policy, int nsteps, const in
 #define ONGYM_LAUNCH_RUN(UA, R)                                                                                    \
     do {                                                                                                           \
         if (policy == ONGYM_POLICY_HIGHEST_SNR)                                                                    \
-            hipLaunchKernelGGL((k_run<true, R, 4, ONGYM_POLICY_HIGHEST_SNR>), grid, block, field_lds(env),          \
+            hipLaunchKernelGGL((k_run<UA, R, 4, ONGYM_POLICY_HIGHEST_SNR>), grid, block, field_lds(env),            \
                                env->stream, env->d_P, mode, nsteps, d_actions, d_act_out, d_flag_out, d_out, policy);      \
         else if (policy == ONGYM_POLICY_LOAD_BALANCING)                                                            \
             hipLaunchKernelGGL((k_run<UA, R, 4, ONGYM_POLICY_LOAD_BALANCING>), grid, block, env->lds, env->stream,  \
@@ -1092,7 +1091,6 @@ int ongym_observe(ongym_env *env, float *obs, uint8_t *mask) {
     if (!env || !obs || !mask) return env ? fail_arg(env, "null obs/mask") : ONGYM_E_ARG;
     const Params &P = env->P;
     if (!P.path_len_norm || !(P.max_bit_rate > 0)) return fail_arg(env, "observation needs path_len_norm and max_bit_rate = max(bit_rates)");
-    if (!P.uniform_alpha) return fail_arg(env, "observation kernel needs uniform attenuation", ONGYM_E_LIMIT);
     if (std::fabs(P.slot_bw - P.channel_width * 1e9) > 1e-6 * P.slot_bw) return fail_arg(env, "observation needs slot_bandwidth == channel_width*1e9");
     HIP_TRY(env, hipSetDevice(env->cfg.device));
     const size_t obs_dim = 3 + P.k_paths + (size_t)P.k_paths * P.n_mods_consider * 12;

@@ -144,6 +144,31 @@ def test_observation_continuous_bit_rates_vs_oracle():
     assert obs[:, 0].max() > 1.0        # a 300 Gb/s request over max(bit_rates) = 100
 
 
+def test_observation_per_link_attenuation_vs_oracle():
+    """Per-link attenuation (a hand-built topology: the reference's loader always gives one value): no pair table, the
+    field builder evaluates every (centre, interferer, shared link) asinh difference itself, the self term is summed over
+    the path's links.  Device vs oracle on loaded states, masks bit-exact."""
+    import copy
+    tb = copy.deepcopy(golden_tables("nsfnet"))
+    tb.link_alpha = tb.link_alpha * np.linspace(0.9, 1.2, tb.n_links)
+    B = 6
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=256, capacity=1024, load=450,
+              bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), auto_reset=True)
+    holder = nat.ConfigHolder(tb, batch=B, **kw)
+    env = BatchedQRMSAEnv(tables=tb, batch_size=B, **kw)
+    env.seed(31); env.reset()
+    env.step_policy(420, record=False)
+    obs, mask = env.observe()
+    pl = np.ctypeslib.as_array(holder.struct.path_len_norm, shape=(holder.struct.n_paths,))
+    for r in range(B):
+        o = OracleEnv(holder, replica=r)
+        o.seed(31); o.reset(); o.run_first_fit(420)
+        want_obs, want_mask = o.observe(pl, holder.struct.max_bit_rate)
+        np.testing.assert_array_equal(mask[r], want_mask, err_msg=f"mask replica {r}")
+        np.testing.assert_allclose(obs[r], want_obs, rtol=2e-6, atol=2e-7, err_msg=f"obs replica {r}")
+    assert mask[:, :-1].any() and not mask[:, :-1].all()
+
+
 def test_masked_actions_are_accepted_by_step():
     """every action the mask allows is feasible: stepping it never raises the QoT error / retry."""
     meta, d = load_traj("obs_nsfnet320_dense")

@@ -314,6 +314,27 @@ def test_nonuniform_attenuation_vs_oracle():
     assert_records_equal(env.step_policy(steps), want, "nonuniform")
 
 
+def test_highest_snr_per_link_attenuation_vs_oracle():
+    """heuristic_highest_snr (policy id 2) with per-link attenuation: the interferer field without the pair table."""
+    import copy
+    tb = copy.deepcopy(golden_tables("nsfnet"))
+    tb.link_alpha = tb.link_alpha * np.linspace(0.9, 1.2, tb.n_links)
+    B, steps = 4, 260
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=128, batch=B, capacity=512, load=200,
+              bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), auto_reset=True, episode_length=200)
+    holder = nat.ConfigHolder(tb, **kw)
+    env = BatchedQRMSAEnv(tables=tb, modulations=jocn_modulations(), batch_size=B, num_spectrum_resources=128,
+                          capacity=512, load=200, bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400),
+                          episode_length=200, auto_reset=True)
+    env.seed(12); env.reset()
+    got = env.step_policy(steps, policy=nat.POLICY_HIGHEST_SNR)
+    for r in range(B):
+        o = OracleEnv(holder, replica=r)
+        o.seed(12); o.reset()
+        assert_records_equal(got[:, r], o.run_policy(nat.POLICY_HIGHEST_SNR, steps), f"highest SNR, per-link alpha, replica {r}")
+        np.testing.assert_array_equal(env.grid(r), o.grid())
+
+
 def test_policy_actions_matches_step_and_is_pure():
     meta, d = load_traj("traj_nsfnet320")
     env = make_env(meta, batch=16, load=450)
