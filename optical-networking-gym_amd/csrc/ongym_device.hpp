@@ -1553,14 +1553,15 @@ __device__ __forceinline__ void field_tile(const Params &P, int lane, double *Fx
 
 // self-channel term of a candidate of n slots on a path: sum over its links of w1_l * asinh(pi^2 |b2| B^2 / (4 alpha_l))
 // (core/osnr.pyx:58-61); one table product when the attenuation is uniform
+template <bool UNIFORM_ALPHA>
 __device__ __forceinline__ double path_self_term(const Ctx &c, const PathRef &p, int n) {
     const Params &P = c.P;
-    if (P.uniform_alpha) return G(P.path_w1)[p.id] * G(P.self_asinh)[n];
+    if (UNIFORM_ALPHA) return G(P.path_w1)[p.id] * G(P.self_asinh)[n];
     const double bw = P.slot_bw * n;
     return wave_sum(c.lane < p.hops ? c.lw[2 * p.mylink] * asinh(c.lsc[p.mylink] * (bw * bw)) : 0.0);
 }
 
-template <bool R32>
+template <bool UNIFORM_ALPHA, bool R32>
 __device__ __forceinline__ void build_field(Ctx &c, const PathRef &p, uint64_t free_ext, const FieldLds &fl) {
     const Params &P = c.P;
     const int M = P.n_mods, S = P.n_slots, nx = 2 * S + 1, W = P.row_words;
@@ -1624,14 +1625,14 @@ __device__ __forceinline__ void build_field(Ctx &c, const PathRef &p, uint64_t f
             uint64_t m0, m1;
             if (R32) { m0 = a & (uint32_t)p.m0; m1 = 0; }
             else { int pk = a & 0xFFFF; m0 = G(P.path_mask)[2 * pk] & p.m0; m1 = G(P.path_mask)[2 * pk + 1] & p.m1; }
-            km0 = m0; km1 = m1; kphi = c.phi[rec_mod<R32>(a, b)];
+            if (!UNIFORM_ALPHA) { km0 = m0; km1 = m1; kphi = c.phi[rec_mod<R32>(a, b)]; }
             double w2 = 0.0;
             while (m0) { int l = __ffsll((unsigned long long)m0) - 1; m0 &= m0 - 1; w1 += c.lw[2 * (l)]; w2 += c.lw[2 * (l) + 1]; }
             while (m1) { int l = 64 + __ffsll((unsigned long long)m1) - 1; m1 &= m1 - 1; w1 += c.lw[2 * (l)]; w2 += c.lw[2 * (l) + 1]; }
             pw2 = c.phi[rec_mod<R32>(a, b)] * w2;
         }
         const int tile_n = min(kWave, L - base);
-        if (!P.uniform_alpha) {
+        if (!UNIFORM_ALPHA) {
             // per-link attenuation: the asinh difference depends on the link (core/osnr.pyx:68-84), no table and no summed
             // weights - every (centre, interferer, shared link) term is evaluated like gn_eval's generic branch does
             for (int x0 = 0; x0 < nxl; x0 += kWave) {
@@ -1721,7 +1722,7 @@ __device__ __forceinline__ void build_field(Ctx &c, const PathRef &p, uint64_t f
     wave_sync();
 }
 
-template <bool R32>
+template <bool UNIFORM_ALPHA, bool R32>
 __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, uint16_t *xlist, uint8_t *needx,
                                             float *obs, uint8_t *mask) {
     const Params &P = c.P;
@@ -1754,14 +1755,14 @@ __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, ui
             if (path < 0) break;
             PathRef p = load_path(c, path);
             const uint64_t free_ext = path_free_ext(c, p);
-            build_field<R32>(c, p, free_ext, FieldLds{Fx, Vw, xlist, needx});
+            build_field<UNIFORM_ALPHA, R32>(c, p, free_ext, FieldLds{Fx, Vw, xlist, needx});
             const double pase = G(P.path_ase)[path];
             for (int mi = 0; mi < Mall && !found; mi++) {
                 const int m = Mall - 1 - mi;
                 const int n = uniform_i32(c.nreq[m]);
                 if (n <= 0 || n > S) continue;
                 const double bw = P.slot_bw * n, lim = c.lim[m];
-                const double self = path_self_term(c, p, n), nlic = G(P.nli_coef)[n] * c.rp[1];
+                const double self = path_self_term<UNIFORM_ALPHA>(c, p, n), nlic = G(P.nli_coef)[n] * c.rp[1];
                 bool pass = false;
                 for (int i = 0; i < W; i++) {
                     const uint64_t w = Vw[mi * kMaxRowWords + i];
@@ -1811,7 +1812,7 @@ __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, ui
         const double len2 = (double)wave_sum_i32(len2_l);
         STAMPW(c, 8);
         // ---- interferer field F(x) at the needed centres + valid starts per modulation (shared builder)
-        build_field<R32>(c, p, free_ext, FieldLds{Fx, Vw, xlist, needx});
+        build_field<UNIFORM_ALPHA, R32>(c, p, free_ext, FieldLds{Fx, Vw, xlist, needx});
         STAMPW(c, 9);
         // ---- per format of the window, best first (mod_list = reversed(modulations[start : start + M]), :716-717); the field
         // builder numbers its valid-start rows from the best of ALL formats: row fi = n_mods - 1 - m
@@ -1836,7 +1837,7 @@ __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, ui
                 continue;
             }
             const double thr = P.mod_thr[m], bw = P.slot_bw * n, inv_thr = 1.0 / fabs(thr);
-            const double self = path_self_term(c, p, n), nlic = G(P.nli_coef)[n] * c.rp[1];
+            const double self = path_self_term<UNIFORM_ALPHA>(c, p, n), nlic = G(P.nli_coef)[n] * c.rp[1];
             // the valid starts of _get_candidates (:590), compacted: ascending slot indices in xlist (free again after the
             // field was built), so that the per-candidate arithmetic runs on dense lanes
             int cnt = 0;
@@ -1917,14 +1918,14 @@ __device__ __forceinline__ void policy_highest_snr(Ctx &c, int src, int dst, dou
         else p = load_path(c, path);
         c.paths_tried++; c.path_hops += p.hops;
         const uint64_t free_ext = path_free_ext(c, p);
-        build_field<R32>(c, p, free_ext, c.fl);
+        build_field<UNIFORM_ALPHA, R32>(c, p, free_ext, c.fl);
         const double pase = G(P.path_ase)[path];
         for (int m = max_mod; m >= 0; m--) {
             const int mi = max_mod - m;
             const int n = uniform_i32(c.nreq[m]);
             if (n <= 0) continue;
             const double thr = P.mod_thr[m] + margin, lim = c.lim[m], bw = P.slot_bw * n;
-            const double self = path_self_term(c, p, n), nlic = G(P.nli_coef)[n] * c.rp[1];
+            const double self = path_self_term<UNIFORM_ALPHA>(c, p, n), nlic = G(P.nli_coef)[n] * c.rp[1];
             int nvalid = 0;
             for (int i = 0; i < W; i++) {
                 const uint64_t w = c.fl.Vw[mi * kMaxRowWords + i];

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64) void k_reset(const Params *__restrict__ Pp, con
 #ifndef ONGYM_OBS_WAVES
 #define ONGYM_OBS_WAVES 3
 #endif
-template <bool R32>
+template <bool UA, bool R32>
 __global__ __launch_bounds__(64, ONGYM_OBS_WAVES) void k_observe(const Params *__restrict__ Pp, float *obs, uint8_t *mask) {
     extern __shared__ __align__(16) unsigned char smem[];
     const Params &P = *Pp;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(64, ONGYM_OBS_WAVES) void k_observe(const Params *_
     uint8_t *needx = reinterpret_cast<uint8_t *>(Vw + kMaxMods * kMaxRowWords);
     wave_sync();
     c.fl = FieldLds{Fx, Vw, xlist, needx};
-    observe_env<R32>(c, Fx, Vw, xlist, needx, obs + (size_t)c.replica * obs_dim, mask + (size_t)c.replica * nact);
+    observe_env<UA, R32>(c, Fx, Vw, xlist, needx, obs + (size_t)c.replica * obs_dim, mask + (size_t)c.replica * nact);
 #ifdef ONGYM_STAMPS
     STAMPW(c, 15);
     if (c.lane == 0 && P.dbg)
@@ -1098,8 +1098,10 @@ int ongym_observe(ongym_env *env, float *obs, uint8_t *mask) {
     const size_t B = (size_t)P.batch;
     const size_t lds = observe_lds(env);
     if (lds > 64 * 1024) {
-        HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_observe<true>), lds));
-        HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_observe<false>), lds));
+        HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_observe<true, true>), lds));
+        HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_observe<true, false>), lds));
+        HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_observe<false, true>), lds));
+        HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_observe<false, false>), lds));
     }
     float *d_obs = obs; uint8_t *d_mask = mask;
     if (!env->cfg.io_device) {
@@ -1113,8 +1115,10 @@ int ongym_observe(ongym_env *env, float *obs, uint8_t *mask) {
     }
     HIP_TRY(env, hipMemsetAsync(d_mask, 0, B * nact, env->stream));     // k_observe only sets the ones
     HIP_TRY(env, hipEventRecord(env->ev0, env->stream));
-    if (P.rec32) hipLaunchKernelGGL(k_observe<true>, dim3(P.batch), dim3(64), lds, env->stream, env->d_P, d_obs, d_mask);
-    else hipLaunchKernelGGL(k_observe<false>, dim3(P.batch), dim3(64), lds, env->stream, env->d_P, d_obs, d_mask);
+#define ONGYM_LAUNCH_OBS(UA, R) hipLaunchKernelGGL((k_observe<UA, R>), dim3(P.batch), dim3(64), lds, env->stream, env->d_P, d_obs, d_mask)
+    if (P.uniform_alpha) { if (P.rec32) ONGYM_LAUNCH_OBS(true, true); else ONGYM_LAUNCH_OBS(true, false); }
+    else { if (P.rec32) ONGYM_LAUNCH_OBS(false, true); else ONGYM_LAUNCH_OBS(false, false); }
+#undef ONGYM_LAUNCH_OBS
     HIP_TRY(env, hipGetLastError());
     HIP_TRY(env, hipEventRecord(env->ev1, env->stream));
     env->timed = true;

@@ -83,6 +83,41 @@ class Service:
                 f"number_slots={self.number_slots}, accepted={self.accepted}, OSNR={self.OSNR})")
 
 
+class _LazyViews(dict):
+    """A `topology.graph` / edge-attribute dict whose state views (`available_slots`, `running_services`) are rebuilt from
+    the device only when something reads them after the state changed: the reference keeps these entries current on every
+    step (qrmsa.pyx:1291-1350); here a step that nobody inspects costs no host-side rebuild."""
+    __slots__ = ("_owner", "_lazy")
+
+    def __init__(self, data, owner, lazy):
+        super().__init__(dict.items(data) if isinstance(data, dict) else data)   # no view rebuild while copying
+        self._owner, self._lazy = owner, frozenset(lazy)
+
+    def _fresh(self, key=None):
+        if key is None or key in self._lazy:
+            self._owner._ensure_views()
+
+    def __getitem__(self, key):
+        self._fresh(key)
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        self._fresh(key)
+        return dict.get(self, key, default)
+
+    def items(self):
+        self._fresh()
+        return dict.items(self)
+
+    def values(self):
+        self._fresh()
+        return dict.values(self)
+
+    def copy(self):
+        self._fresh()
+        return dict(self)
+
+
 class QRMSAEnv:
     def __init__(self, topology, num_spectrum_resources: int = 320, episode_length: int = 1000, load: float = 10.0,
                  mean_service_holding_time: float = 10800.0, bit_rate_selection: str = "continuous",
@@ -172,6 +207,14 @@ class QRMSAEnv:
             # the reference's traffic RNG is unseeded (quirk Q2); here `seed` selects the device stream
             self._dev.seed(self.input_seed)
         self._sync_views = bool(sync_views)
+        self._state_version, self._views_version = 1, 0
+        if self._sync_views:   # the state views are rebuilt on first read after a change (see _LazyViews)
+            if not isinstance(topology.graph, _LazyViews) or topology.graph._owner is not self:
+                topology.graph = _LazyViews(topology.graph, self, ("available_slots", "running_services"))
+            for u, v in topology.edges():
+                lv = _LazyViews(topology._adj[u][v], self, ("running_services",))
+                topology._adj[u][v] = lv
+                topology._adj[v][u] = lv
         self.file_stats = None
         if file_name != "":   # per-service CSV of qrmsa.pyx:387-406, same name pattern and header
             final_name = "_".join([file_name, str(topology.graph["name"]), str(self.launch_power_dbm), str(self.load),
@@ -204,8 +247,16 @@ class QRMSAEnv:
             holding_time=float(q["holding_time"]), bit_rate=float(q["bit_rate"]))
 
     def _refresh_views(self):
-        if not self._sync_views:
+        """The device state changed: the views are stale.  With defragmentation the rebuild also replays moved services
+        onto the listed Service objects, which readers reach without touching a view, so it stays eager."""
+        self._state_version += 1
+        if self.defragmentation:
+            self._ensure_views()
+
+    def _ensure_views(self):
+        if not self._sync_views or self._views_version == self._state_version:
             return
+        self._views_version = self._state_version      # first: the rebuild itself reads and writes the dicts
         g = self.topology.graph
         g["available_slots"] = self._dev.grid(0)
         running = []
@@ -264,6 +315,7 @@ class QRMSAEnv:
         self.max_modulation_idx = len(self.modulations) - 1
         self._pull_request()
         self._refresh_views()
+        self._ensure_views()           # once per reset: the view keys exist from here on
         obs, mask = self._blank_observation()
         return obs, dict(mask)
 
