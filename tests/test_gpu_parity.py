@@ -141,7 +141,9 @@ def run_oracle_batch(holder, seed, nsteps, batch):
 
 
 @pytest.mark.parametrize("topo,S,load,steps", [("nsfnet", 320, 300, 1300), ("cost239", 320, 400, 700),
-                                                ("nobel-eu", 768, 600, 700), ("germany50", 320, 500, 400)])
+                                                ("nobel-eu", 768, 600, 700), ("germany50", 320, 500, 400),
+                                                # slot counts that are not a multiple of the bitmap word (lean kernel: 32)
+                                                ("nsfnet", 100, 120, 500), ("nsfnet", 333, 350, 500), ("nobel-eu", 417, 500, 400)])
 def test_random_traffic_vs_oracle(topo, S, load, steps):
     """Device request generator + fused step vs the CPU oracle on the same (seed, replica) streams, B=48 replicas with
     per-replica load / launch power / margin overrides; crosses an episode boundary (auto-reset)."""
