@@ -68,3 +68,25 @@ def test_drivers_defragmentation_columns_and_plugin_path(tmp_path):
     assert len(out) == 1 and 0.0 <= out[0][0] <= 1.0
     rows = list(csv.reader(l for l in open(tmp_path / "plugin.csv") if not l.startswith("#")))
     assert len(rows) == 2 and len(rows[1]) == len(rows[0])
+
+
+@pytest.mark.parametrize("policy", [10, 11])
+def test_scored_policies_drive_a_batched_sweep(tmp_path, policy):
+    """graph_load.py -hi 3 (lowest fragmentation) and graph_launch_power.py -hi 5 (full MSCL) run as fused device policies
+    (ids 10, 11): a small sweep writes the reference's CSV columns and sane blocking rates."""
+    import csv
+    import jocn_common as J
+    topology = J.load_topology("nsfnet_chen.txt", 5)
+    common = dict(load=300.0, num_spectrum_resources=128, bit_rate_selection="discrete", bit_rates=(10, 40, 100),
+                  launch_power_dbm=1.0, capacity=512)
+    names = [str(tmp_path / f"p{policy}_{ld}.csv") for ld in (150, 400)]
+    res = J.run_sweep(topology, n_episodes=4, episode_length=150, replicas_per_point=4, seed=5, common=common,
+                      points=[dict(load=150.0), dict(load=400.0)], monitor_names=names, policy=policy)
+    assert all(len(r) == 4 and ((0.0 <= r) & (r <= 1.0)).all() for r in res)
+    if policy == 10:       # sized slots + 1: a third of the decisions fail the step's own GSNR check and are rejected
+        assert res[0].mean() > 0.1
+    else:
+        assert res[0].mean() <= res[1].mean() + 0.05
+    for name in names:
+        rows = list(csv.reader(l for l in open(name) if not l.startswith("#")))
+        assert len(rows) == 5 and all(len(r) == len(rows[0]) for r in rows)
