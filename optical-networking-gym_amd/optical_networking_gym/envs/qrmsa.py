@@ -477,6 +477,30 @@ class QRMSAEnv:
         route = self.k_shortest_paths[self.current_service.source, self.current_service.destination][path]
         return [grid[self.topology[l.node1][l.node2]["index"], :] for l in route.links]
 
+    def _get_network_compactness(self) -> float:
+        """Spectrum compactness of the whole network, qrmsa.pyx:1150-1186: (occupied span summed over links / slot-hops of the
+        running services) x (links / free blocks inside the occupied spans); 1.0 when no link has a free block inside its
+        occupied span.  Parity unpinned: the compiled reference segfaults in this method (its `rle` is handed a row of the wrong
+        element type), so no output of it exists to compare with - this is the arithmetic of the source text on the device-
+        backed views.  (An empty network returns 1.0 here; the source text would divide by zero slot-hops only if a link held
+        two used blocks without any running service, which cannot happen.)"""
+        slot_hops = sum(s.number_slots * s.path.hops for s in self.topology.graph["running_services"])
+        grid = np.asarray(self.topology.graph["available_slots"])
+        occupied = unused_blocks = 0.0
+        for n1, n2 in self.topology.edges():
+            row = grid[self.topology[n1][n2]["index"], :]
+            starts, values, lengths = rle(row)
+            used = np.flatnonzero(values == 0)
+            if len(used) > 1:
+                lo = int(starts[used[0]])
+                hi = int(starts[used[-1]] + lengths[used[-1]])
+                occupied += hi - lo
+                _, inner_values, _ = rle(row[lo:hi])
+                unused_blocks += float(np.sum(inner_values))        # one per run of value 1 inside the span
+        if unused_blocks > 0:
+            return (occupied / slot_hops) * (self.topology.number_of_edges() / unused_blocks)
+        return 1.0
+
     def _update_link_stats(self, node1, node2) -> None:
         """Time-weighted utilisation / external fragmentation / compactness of one link (qrmsa.pyx:1353-1480), written
         to the edge attributes like the reference.  Host-side arithmetic on the device's grid view; nothing in the

@@ -231,8 +231,9 @@ def test_defragmentation_through_the_wrapper():
 
 def test_link_statistics_like_the_reference():
     """_update_link_stats (qrmsa.pyx:1353-1480) on the device-backed env against values obtained by calling the
-    reference's method on the same states (tests/golden/linkstats_nsfnet320.*).  (_get_network_compactness, :1150-1186,
-    segfaults in the compiled reference and is not provided.)"""
+    reference's method on the same states (tests/golden/linkstats_nsfnet320.*).  _get_network_compactness (:1150-1186)
+    segfaults in the compiled reference, so it has no fixture: PARITY UNPINNED - it is checked against a slot-by-slot
+    recomputation of the source text's definition on the same state."""
     import json, os
     from common import GOLDEN
     meta = json.load(open(os.path.join(GOLDEN, "linkstats_nsfnet320.json")))
@@ -258,6 +259,21 @@ def test_link_statistics_like_the_reference():
                 link = sim.topology[u][v]
                 have = [link["utilization"], link["external_fragmentation"], link["compactness"], link["last_update"]]
                 np.testing.assert_allclose(have, want, rtol=1e-12, atol=1e-15)
+            # network compactness, recomputed slot by slot (parity unpinned, see the docstring)
+            grid = np.asarray(sim.topology.graph["available_slots"])
+            slot_hops = sum(s.number_slots * s.path.hops for s in sim.topology.graph["running_services"])
+            occupied = unused = 0
+            for u, v in sim.topology.edges():
+                row = [int(x) for x in grid[sim.topology[u][v]["index"]]]
+                blocks = [j for j in range(len(row)) if row[j] == 0 and (j == 0 or row[j - 1] != 0)]      # used-block starts
+                if len(blocks) > 1:
+                    lo = blocks[0]
+                    hi = max(j for j in range(len(row)) if row[j] == 0) + 1
+                    occupied += hi - lo
+                    unused += sum(1 for j in range(lo, hi) if row[j] == 1 and (j == lo or row[j - 1] != 1))
+            want_c = (occupied / slot_hops) * (sim.topology.number_of_edges() / unused) if unused else 1.0
+            assert sim._get_network_compactness() == pytest.approx(want_c, rel=1e-12)
+            assert unused > 0 and want_c > 0
 
 
 def test_counters_only_reset_through_the_gym_surface():
