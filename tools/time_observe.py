@@ -17,11 +17,14 @@ for B in batches:
                           load=wl["load"], bit_rate_selection="discrete", bit_rates=wl["bit_rates"])
     env.seed(1); env.reset()
     env.step_policy(600, record=False)
-    ms = []
+    ms, ms_pol, ms_step = [], [], []
     for _ in range(5):
         obs, mask = env.observe()
         ms.append(env.last_kernel_ms())
         acts, _ = env.policy_actions()
+        ms_pol.append(env.last_kernel_ms())
         env.step(acts)
+        ms_step.append(env.last_kernel_ms())
     print(f"B={B}: observe kernel {np.median(ms):.3f} ms -> {B / np.median(ms) * 1e3:.3e} observations/s; "
-          f"mask ones/replica {mask[:, :-1].sum() / B:.0f}")
+          f"mask ones/replica {mask[:, :-1].sum() / B:.0f}; policy_actions kernel {np.median(ms_pol):.3f} ms, "
+          f"step(actions) kernel {np.median(ms_step):.3f} ms")
