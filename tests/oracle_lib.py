@@ -12,7 +12,7 @@ from optical_networking_gym._native import (ConfigHolder, OngymConfig, REQUEST_D
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(REPO, "oracle")
-ORACLE_LIB = os.path.join(ORACLE_DIR, "libongym_oracle.so")
+ORACLE_LIB = os.environ.get("ONGYM_ORACLE_LIB") or os.path.join(ORACLE_DIR, "libongym_oracle.so")   # override: sanitizer builds
 
 _lib = None
 
@@ -22,6 +22,8 @@ def build_oracle(force: bool = False) -> str:
     stale = (not os.path.exists(ORACLE_LIB)) or any(
         os.path.getmtime(p) > os.path.getmtime(ORACLE_LIB)
         for p in (src, os.path.join(REPO, "include", "ongym.h"), os.path.join(REPO, "include", "ongym_traffic.h")))
+    if os.environ.get("ONGYM_ORACLE_LIB"):
+        return ORACLE_LIB
     if force or stale:
         subprocess.run(["make", "-C", ORACLE_DIR, "-B", "libongym_oracle.so"], check=True, stdout=subprocess.DEVNULL)
     return ORACLE_LIB
