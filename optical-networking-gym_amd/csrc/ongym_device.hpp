@@ -151,13 +151,48 @@ __host__ __device__ inline size_t lds_bytes(const Params &P) {
 #define STAMPW(c, idx) do { } while (0)
 #endif
 
-// k_observe: can the valid-start words and the need flags live where the state block keeps the release times?
-__host__ __device__ inline bool obs_alias_sr(const Params &P) {
-    return (size_t)P.capacity * 4 >= (size_t)kMaxMods * kMaxRowWords * 8 + (size_t)2 * P.n_slots + 2 + 8;
-}
-
 // extra LDS of the kernels that evaluate EVERY candidate of a path (observation, highest-SNR policy)
-struct FieldLds { double *Fx; uint64_t *Vw; uint16_t *xlist; uint8_t *needx; };
+//   Fx f64[2S+2] interferer field at half-slot centres | xlist u16[2S+2] needed centres, then candidate starts |
+//   Vw u64[n_mods][vs] valid-start words per format (word per lane) | needx u8[2S+2] "centre needed" flags
+struct FieldLds { double *Fx; uint64_t *Vw; uint16_t *xlist; uint8_t *needx; int vs; };
+
+// LDS block of k_observe (byte offsets from the start of the workgroup's LDS; host and device use the same function).
+// The observation never reads the release times `sr` nor, outside build_field, the interferer index list `list`:
+//   compact (list is the LAST array of the state block, i.e. no id / disruption arrays, and `sr` is large enough):
+//       Vw (stride ext_words) and needx live in `sr`; `list` OVERLAYS needx - build_field compacts the needed centres before it
+//       builds the list - and Fx, xlist start where `list` was: 14 636 -> 13 740 B for NSFNET-320 / C = 448, i.e. 11 instead of
+//       10 resident blocks per CU (LDS is allocated in 1 280-byte granules)
+//   alias: Vw (stride 16) and needx in `sr`, `list` stays, Fx and xlist after the state block
+//   plain: everything after the state block
+struct ObsLayout { size_t fx, xlist, vw, needx, list, total; int vs; };
+__host__ __device__ inline size_t lds_list_offset(const Params &P) {
+    return (size_t)P.n_links * P.row_words * 8 + (size_t)P.n_links * (P.uniform_alpha ? 16 : 32) + kEnvHotBytes +
+           (64 + 16 + 64 + 128 + 32) + (size_t)P.capacity * 12;
+}
+__host__ __device__ inline ObsLayout obs_layout(const Params &P) {
+    ObsLayout o;
+    const size_t nxb = (size_t)2 * P.n_slots + 2;
+    const size_t sr = lds_list_offset(P) - (size_t)P.capacity * 4, cap4 = (size_t)P.capacity * 4;
+    const size_t vw_c = (size_t)P.n_mods * P.ext_words * 8, needx_b = (nxb + 7) & ~(size_t)7, list_b = (size_t)P.capacity * 2;
+    const bool list_last = !P.track_ids && !P.measure_disruptions;
+    if (list_last && cap4 >= vw_c + (needx_b > list_b ? needx_b : list_b)) {
+        o.vs = P.ext_words; o.vw = sr; o.needx = sr + vw_c; o.list = o.needx;
+        o.fx = (lds_list_offset(P) + 15) & ~(size_t)15;
+        o.xlist = o.fx + nxb * 8;
+        o.total = o.xlist + nxb * 2;
+    } else if (cap4 >= (size_t)kMaxMods * kMaxRowWords * 8 + nxb + 8) {
+        o.vs = kMaxRowWords; o.vw = (sr + 7) & ~(size_t)7; o.needx = o.vw + (size_t)kMaxMods * kMaxRowWords * 8; o.list = lds_list_offset(P);
+        o.fx = lds_bytes(P); o.xlist = o.fx + nxb * 8;
+        o.total = o.xlist + nxb * 2;
+    } else {
+        o.vs = kMaxRowWords; o.list = lds_list_offset(P);
+        o.fx = lds_bytes(P); o.xlist = o.fx + nxb * 8;
+        o.vw = (o.xlist + nxb * 2 + 7) & ~(size_t)7; o.needx = o.vw + (size_t)kMaxMods * kMaxRowWords * 8;
+        o.total = o.needx + nxb;
+    }
+    o.total = (o.total + 15) & ~(size_t)15;
+    return o;
+}
 
 struct Ctx {
 #ifdef ONGYM_STAMPS
@@ -1566,9 +1601,8 @@ __device__ __forceinline__ void build_field(Ctx &c, const PathRef &p, uint64_t f
     const Params &P = c.P;
     const int M = P.n_mods, S = P.n_slots, nx = 2 * S + 1, W = P.row_words;
     double *Fx = fl.Fx; uint64_t *Vw = fl.Vw; uint16_t *xlist = fl.xlist; uint8_t *needx = fl.needx;
+    const int vs = fl.vs;
     STAMPW(c, 1);
-    const int L = gn_build_list<R32>(c, p.m0, p.m1);
-    STAMPW(c, 2);
     // valid starts of every modulation (run-AND words, lane w = word w) and the candidate centres x = 2s + n they
     // produce: the field is only needed there (a loaded network has few valid starts)
     for (int x = c.lane; x < nx + 1; x += kWave) { Fx[x] = 0.0; needx[x] = 0; }
@@ -1583,14 +1617,14 @@ __device__ __forceinline__ void build_field(Ctx &c, const PathRef &p, uint64_t f
                 runs0 = run_and(runs0, r0, n + 1);
                 v = runs0;
             }
-            if (c.lane < kMaxRowWords) Vw[mi * kMaxRowWords + c.lane] = v;
+            if (c.lane < vs) Vw[mi * vs + c.lane] = v;
         }
     }
     wave_sync();
     STAMPW(c, 3);
     for (int mi = 0; mi < M; mi++) {
         const int n = uniform_i32(c.nreq[M - 1 - mi]);
-        const uint64_t vrow = Vw[mi * kMaxRowWords + min(c.lane, kMaxRowWords - 1)];        // lane i = word i
+        const uint64_t vrow = Vw[mi * vs + min(c.lane, vs - 1)];        // lane i = word i
         for (int i = 0; i < W; i++) {
             const uint64_t w = readlane_u64(vrow, i);
             if (!w) continue;
@@ -1610,6 +1644,9 @@ __device__ __forceinline__ void build_field(Ctx &c, const PathRef &p, uint64_t f
     }
     wave_sync();
     STAMPW(c, 5);
+    // the interferer list is built only now: in k_observe's compact layout it overlays needx, which is dead from here on
+    const int L = gn_build_list<R32>(c, p.m0, p.m1);
+    STAMPW(c, 2);
     for (int base = 0; base < L; base += kWave) {
         const int j = base + c.lane;
         int c2k = 0, nk = 0;
@@ -1723,7 +1760,7 @@ __device__ __forceinline__ void build_field(Ctx &c, const PathRef &p, uint64_t f
 }
 
 template <bool UNIFORM_ALPHA, bool R32>
-__device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, uint16_t *xlist, uint8_t *needx,
+__device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, uint16_t *xlist, uint8_t *needx, int vs,
                                             float *obs, uint8_t *mask) {
     const Params &P = c.P;
     const int K = P.k_paths, Mall = P.n_mods, M = P.n_mods_consider, S = P.n_slots, N = P.n_nodes;
@@ -1755,7 +1792,7 @@ __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, ui
             if (path < 0) break;
             PathRef p = load_path(c, path);
             const uint64_t free_ext = path_free_ext(c, p);
-            build_field<UNIFORM_ALPHA, R32>(c, p, free_ext, FieldLds{Fx, Vw, xlist, needx});
+            build_field<UNIFORM_ALPHA, R32>(c, p, free_ext, FieldLds{Fx, Vw, xlist, needx, vs});
             const double pase = G(P.path_ase)[path];
             for (int mi = 0; mi < Mall && !found; mi++) {
                 const int m = Mall - 1 - mi;
@@ -1765,7 +1802,7 @@ __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, ui
                 const double self = path_self_term<UNIFORM_ALPHA>(c, p, n), nlic = G(P.nli_coef)[n] * c.rp[1];
                 bool pass = false;
                 for (int i = 0; i < W; i++) {
-                    const uint64_t w = Vw[mi * kMaxRowWords + i];
+                    const uint64_t w = Vw[mi * vs + i];
                     const int s0 = i * 64 + c.lane;
                     if (((w >> c.lane) & 1ull) && s0 < S) {
                         const double fc = P.f0 + (P.slot_bw * s0) + (P.slot_bw * (n / 2.0));
@@ -1812,7 +1849,7 @@ __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, ui
         const double len2 = (double)wave_sum_i32(len2_l);
         STAMPW(c, 8);
         // ---- interferer field F(x) at the needed centres + valid starts per modulation (shared builder)
-        build_field<UNIFORM_ALPHA, R32>(c, p, free_ext, FieldLds{Fx, Vw, xlist, needx});
+        build_field<UNIFORM_ALPHA, R32>(c, p, free_ext, FieldLds{Fx, Vw, xlist, needx, vs});
         STAMPW(c, 9);
         // ---- per format of the window, best first (mod_list = reversed(modulations[start : start + M]), :716-717); the field
         // builder numbers its valid-start rows from the best of ALL formats: row fi = n_mods - 1 - m
@@ -1841,7 +1878,7 @@ __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, ui
             // the valid starts of _get_candidates (:590), compacted: ascending slot indices in xlist (free again after the
             // field was built), so that the per-candidate arithmetic runs on dense lanes
             int cnt = 0;
-            const uint64_t vrow = Vw[fi * kMaxRowWords + min(c.lane, kMaxRowWords - 1)];    // lane i = word i
+            const uint64_t vrow = Vw[fi * vs + min(c.lane, vs - 1)];    // lane i = word i
             for (int i = 0; i < W; i++) {
                 uint64_t w = readlane_u64(vrow, i);
                 if (i == (S >> 6)) w &= ~(1ull << (S & 63));              // the virtual slot S is not a start
@@ -1928,7 +1965,7 @@ __device__ __forceinline__ void policy_highest_snr(Ctx &c, int src, int dst, dou
             const double self = path_self_term<UNIFORM_ALPHA>(c, p, n), nlic = G(P.nli_coef)[n] * c.rp[1];
             int nvalid = 0;
             for (int i = 0; i < W; i++) {
-                const uint64_t w = c.fl.Vw[mi * kMaxRowWords + i];
+                const uint64_t w = c.fl.Vw[mi * c.fl.vs + i];
                 if (!w) continue;
                 const int s = i * 64 + c.lane;
                 const bool valid = ((w >> c.lane) & 1ull) && s < S;

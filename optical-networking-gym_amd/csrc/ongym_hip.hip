@@ -45,6 +45,7 @@ __global__ __launch_bounds__(64, WAVES) void k_run(const Params *__restrict__ Pp
         c.fl.Vw = reinterpret_cast<uint64_t *>(c.fl.Fx + 2 * P.n_slots + 2);
         c.fl.xlist = reinterpret_cast<uint16_t *>(c.fl.Vw + kMaxMods * kMaxRowWords);
         c.fl.needx = reinterpret_cast<uint8_t *>(c.fl.xlist + 2 * P.n_slots + 2);
+        c.fl.vs = kMaxRowWords;
     }
     load_state(c);
     STAMP(c, 8);
@@ -155,19 +156,17 @@ __global__ __launch_bounds__(64, ONGYM_OBS_WAVES) void k_observe(const Params *_
 #endif
     load_state(c);
     STAMPW(c, 0);
-    double *Fx = reinterpret_cast<double *>(smem + lds_bytes(P));
     const size_t obs_dim = 3 + P.k_paths + (size_t)P.k_paths * P.n_mods_consider * 12;
     const size_t nact = (size_t)P.k_paths * P.n_mods_consider * P.n_slots + 1;
-    // extra LDS of the observation kernel: Fx f64[2S+2] | xlist u16[2S+2] | Vw u64[8*16] | needx u8[2S+2].  The observation
-    // never looks at the release times, so Vw and needx take their place in the state block when they fit
-    // (observe_lds on the host makes the same choice).
-    uint16_t *xlist = reinterpret_cast<uint16_t *>(Fx + 2 * P.n_slots + 2);
-    uint64_t *Vw = obs_alias_sr(P) ? reinterpret_cast<uint64_t *>((reinterpret_cast<uintptr_t>(c.sr) + 7) & ~(uintptr_t)7)
-                                   : reinterpret_cast<uint64_t *>((reinterpret_cast<uintptr_t>(xlist + 2 * P.n_slots + 2) + 7) & ~(uintptr_t)7);
-    uint8_t *needx = reinterpret_cast<uint8_t *>(Vw + kMaxMods * kMaxRowWords);
+    const ObsLayout lay = obs_layout(P);          // observe_lds on the host sizes the block with the same function
+    double *Fx = reinterpret_cast<double *>(smem + lay.fx);
+    uint16_t *xlist = reinterpret_cast<uint16_t *>(smem + lay.xlist);
+    uint64_t *Vw = reinterpret_cast<uint64_t *>(smem + lay.vw);
+    uint8_t *needx = smem + lay.needx;
+    c.list = reinterpret_cast<uint16_t *>(smem + lay.list);
     wave_sync();
-    c.fl = FieldLds{Fx, Vw, xlist, needx};
-    observe_env<UA, R32>(c, Fx, Vw, xlist, needx, obs + (size_t)c.replica * obs_dim, mask + (size_t)c.replica * nact);
+    c.fl = FieldLds{Fx, Vw, xlist, needx, lay.vs};
+    observe_env<UA, R32>(c, Fx, Vw, xlist, needx, lay.vs, obs + (size_t)c.replica * obs_dim, mask + (size_t)c.replica * nact);
 #ifdef ONGYM_STAMPS
     STAMPW(c, 15);
     if (c.lane == 0 && P.dbg)
@@ -926,12 +925,7 @@ int ongym_reset_episode_counters(ongym_env *env, const uint8_t *mask) {
     return ONGYM_OK;
 }
 
-static size_t observe_lds(const ongym_env *env) {   // k_observe: state block + Fx, xlist (+ Vw, needx unless they alias svc_r)
-    const Params &P = env->P;
-    size_t b = env->lds + ((size_t)2 * P.n_slots + 2) * (sizeof(double) + 2) + 8;
-    if (!obs_alias_sr(P)) b += kMaxMods * kMaxRowWords * 8 + (size_t)2 * P.n_slots + 2 + 8;
-    return (b + 15) & ~(size_t)15;
-}
+static size_t observe_lds(const ongym_env *env) { return obs_layout(env->P).total; }   // k_observe's block (ongym_device.hpp)
 
 static size_t field_lds(const ongym_env *env) {   // k_observe / highest-SNR k_run: state block + Fx, Vw, xlist, needx
     const Params &P = env->P;
