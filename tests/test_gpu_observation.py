@@ -99,14 +99,17 @@ def test_modulations_to_consider_vs_oracle_mask_driven():
         env.step_policy(1, policy=nat.POLICY_LOAD_BALANCING)      # only first fit is fused for a narrow codec
 
 
-@pytest.mark.parametrize("topo,S,load", [("nsfnet", 320, 500), ("nobel-eu", 320, 700), ("cost239", 192, 300)])
-def test_observation_vs_oracle_random_states(topo, S, load):
+# capacity decides where k_observe keeps its scratch (obs_layout): 1024 -> compact (inside the release-time slots, list
+# overlaid), 128 -> too small for that: everything after the state block
+@pytest.mark.parametrize("topo,S,load,capacity", [("nsfnet", 320, 500, 1024), ("nobel-eu", 320, 700, 1024),
+                                                   ("cost239", 192, 300, 1024), ("nsfnet", 320, 40, 128)])
+def test_observation_vs_oracle_random_states(topo, S, load, capacity):
     B = 12
-    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=S, batch=B, capacity=1024, load=load,
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=S, batch=B, capacity=capacity, load=load,
               bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), auto_reset=True)
     holder = nat.ConfigHolder(golden_tables(topo), **kw)
     env = BatchedQRMSAEnv(tables=golden_tables(topo), modulations=jocn_modulations(), batch_size=B,
-                          num_spectrum_resources=S, capacity=1024, load=load, bit_rate_selection="discrete",
+                          num_spectrum_resources=S, capacity=capacity, load=load, bit_rate_selection="discrete",
                           bit_rates=(10, 40, 100, 400))
     env.seed(77); env.reset()
     env.step_policy(450, record=False)
