@@ -195,6 +195,39 @@ def test_random_traffic_vs_oracle(topo, S, load, steps):
         assert a.tobytes() == b.tobytes()
 
 
+@pytest.mark.parametrize("case", range(14))
+def test_randomised_configurations_vs_oracle(case):
+    """Configurations drawn at random (topology, slot count - mostly not a multiple of the bitmap word -, routes per pair, bit
+    rate set, load, launch power, margin, episode length): fused first fit + step on device vs the
+    oracle, records bit-exact, crossing several episode boundaries."""
+    rng = np.random.default_rng(1000 + case)
+    topo = ["nsfnet", "cost239", "ring4", "nobel-eu"][int(rng.integers(0, 4))]
+    tb = golden_tables(topo)
+    k = int(rng.integers(1, tb.k_paths + 1))
+    if k < tb.k_paths:
+        tb = tb.truncated(k)
+    S = int(rng.integers(40, 420))
+    all_rates = np.array([10, 25, 40, 100, 200, 400])
+    rates = tuple(int(x) for x in np.sort(rng.choice(all_rates, size=int(rng.integers(1, 5)), replace=False)))
+    B, steps = 6, 950
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=S, capacity=512, load=float(rng.uniform(80, 250) * S / 100),
+              bit_rate_selection="discrete", bit_rates=rates, auto_reset=True, episode_length=int(rng.integers(200, 450)),
+              launch_power_dbm=float(rng.uniform(-3, 3)), margin=float(rng.choice([0.0, 0.5, 1.0])))
+    holder = nat.ConfigHolder(tb, batch=B, **kw)
+    env = BatchedQRMSAEnv(tables=tb, batch_size=B, **kw)
+    env.seed(77 + case); env.reset()
+    got = env.step_policy(steps)
+    rejected = 0
+    for r in range(B):
+        o = OracleEnv(holder, replica=r)
+        o.seed(77 + case); o.reset()
+        want = o.run_first_fit(steps)
+        assert_records_equal(got[:, r], want, f"case {case}: {topo} S={S} k={k} rates={rates} replica {r}")
+        np.testing.assert_array_equal(env.grid(r), o.grid())
+        rejected += int((want["accepted"] == 0).sum())
+    assert got["terminated"].sum() >= 2 * B
+
+
 def test_sharded_batch_equals_unsharded_bit_exact():
     """A batch split over two environments with replica bases 0 and B/2 (what two ranks of bench.py / a sharded sweep
     own, `shard_bounds`) reproduces the single environment of B replicas bit for bit: per-replica statistics, grids and
