@@ -195,11 +195,14 @@ def test_random_traffic_vs_oracle(topo, S, load, steps):
         assert a.tobytes() == b.tobytes()
 
 
+@pytest.mark.parametrize("generic", [False, True], ids=["lean", "generic"])
 @pytest.mark.parametrize("case", range(14))
-def test_randomised_configurations_vs_oracle(case):
+def test_randomised_configurations_vs_oracle(case, generic, monkeypatch):
     """Configurations drawn at random (topology, slot count - mostly not a multiple of the bitmap word -, routes per pair, bit
     rate set, load, launch power, margin, episode length): fused first fit + step on device vs the
     oracle, records bit-exact, crossing several episode boundaries."""
+    if generic:
+        monkeypatch.setenv("ONGYM_FORCE_GENERIC", "1")       # k_run instead of k_fast (read at ongym_create)
     rng = np.random.default_rng(1000 + case)
     topo = ["nsfnet", "cost239", "ring4", "nobel-eu"][int(rng.integers(0, 4))]
     tb = golden_tables(topo)
@@ -216,6 +219,7 @@ def test_randomised_configurations_vs_oracle(case):
     holder = nat.ConfigHolder(tb, batch=B, **kw)
     env = BatchedQRMSAEnv(tables=tb, batch_size=B, **kw)
     env.seed(77 + case); env.reset()
+    assert env.occupancy()["lean_kernel"] == (not generic)       # every drawn configuration is eligible for k_fast
     got = env.step_policy(steps)
     rejected = 0
     for r in range(B):
