@@ -124,6 +124,36 @@ def test_observation_vs_oracle_random_states(topo, S, load, capacity):
     assert mask[:, -1].all() and mask[:, :-1].any()
 
 
+@pytest.mark.parametrize("case", range(8))
+def test_observation_randomised_configurations_vs_oracle(case):
+    """Observation + mask on configurations drawn at random (topology, slot count, routes per pair, bit rates, load, power,
+    margin), after a first-fit warm-up, against the oracle: masks bit-exact, observations within float32 rounding."""
+    rng = np.random.default_rng(500 + case)
+    topo = ["nsfnet", "cost239", "ring4", "nobel-eu"][int(rng.integers(0, 4))]
+    tb = golden_tables(topo)
+    k = int(rng.integers(1, tb.k_paths + 1))
+    if k < tb.k_paths:
+        tb = tb.truncated(k)
+    S = int(rng.integers(40, 420))
+    rates = tuple(int(x) for x in np.sort(rng.choice(np.array([10, 25, 40, 100, 200, 400]), size=int(rng.integers(1, 5)), replace=False)))
+    B, warm = 5, int(rng.integers(60, 400))
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=S, capacity=512, load=float(rng.uniform(60, 200) * S / 100),
+              bit_rate_selection="discrete", bit_rates=rates, auto_reset=True, episode_length=1000,
+              launch_power_dbm=float(rng.uniform(-3, 3)), margin=float(rng.choice([0.0, 0.5, 1.0])))
+    holder = nat.ConfigHolder(tb, batch=B, **kw)
+    env = BatchedQRMSAEnv(tables=tb, batch_size=B, **kw)
+    env.seed(9 + case); env.reset()
+    env.step_policy(warm, record=False)
+    obs, mask = env.observe()
+    pl = np.ctypeslib.as_array(holder.struct.path_len_norm, shape=(holder.struct.n_paths,))
+    for r in range(B):
+        o = OracleEnv(holder, replica=r)
+        o.seed(9 + case); o.reset(); o.run_first_fit(warm)
+        want_obs, want_mask = o.observe(pl, holder.struct.max_bit_rate)
+        np.testing.assert_array_equal(mask[r], want_mask, err_msg=f"case {case}: {topo} S={S} k={k} rates={rates} mask replica {r}")
+        np.testing.assert_allclose(obs[r], want_obs, rtol=2e-6, atol=2e-7, err_msg=f"case {case}: obs replica {r}")
+
+
 def test_observation_continuous_bit_rates_vs_oracle():
     """bit_rate_selection="continuous" (randint bit rates, slot counts by ceil): the observation normalises the bit rate by
     max(bit_rates) of the otherwise unused tuple (qrmsa.pyx:679, 688); device vs oracle on loaded states."""
