@@ -191,7 +191,8 @@ __device__ __forceinline__ void policy_scored(Ctx &c, int policy, int src, int d
         //        LOSS[m][start] = sum over bit rates of PH_w[min(start+n, S)] - PH_w[max(0, start-w+1)],  w = slots(bit rate, m).
         //    The distinct widths of all (format, bit rate) pairs (a bitmap WB, word per lane) are served by ONE pass over the
         //    routes: a route's row is loaded once and the run-AND ladder extended width by width (ascending).
-        //    (The reference's route list holds every route twice, once per direction: a uniform factor 2 on every loss.)
+        //    (The reference's route list holds every route twice, once per direction: a uniform factor 2 on every loss;
+        //    the device visits the (a, d) entries with a < d only.)
         uint64_t WB = 0;
         for (int m = max_mod; m >= 0; m--) {
             if (!any_bits(c.lane < kMaxRowWords ? OKB[m * kMaxRowWords + c.lane] : 0ull)) continue;
@@ -226,18 +227,26 @@ __device__ __forceinline__ void policy_scored(Ctx &c, int policy, int src, int d
                     if (c.lane == i - i0) wv = w;
                 }
             }
-            for (int cbase = 0; cbase < P.n_paths; cbase += kWave) {            // 64 routes of the network per ballot
+            // the routes of the network = the entries of the (pair, k) table, as the reference's dict of k routes per node pair
+            // lists them (:671-674; with fewer routes per pair than the topology holds, only those); one direction per pair
+            const int NK = P.n_nodes * K, n_entries = P.n_nodes * NK;
+            for (int cbase = 0; cbase < n_entries; cbase += kWave) {             // 64 table entries per ballot
                 const int t = cbase + c.lane;
                 bool touch = false;
-                if (t < P.n_paths) touch = ((G(P.path_mask)[2 * t] & p.m0) | (G(P.path_mask)[2 * t + 1] & p.m1)) != 0;
+                int myq = -1;
+                if (t < n_entries) {
+                    const int a = t / NK, d = (t / K) % P.n_nodes;
+                    if (a < d) myq = G(P.pair_paths)[t];
+                    if (myq >= 0) touch = ((G(P.path_mask)[2 * myq] & p.m0) | (G(P.path_mask)[2 * myq + 1] & p.m1)) != 0;
+                }
                 uint64_t bal = __ballot(touch);
                 if (!bal) continue;
-                int q = cbase + __ffsll((unsigned long long)bal) - 1;
+                int q = __builtin_amdgcn_readlane(myq, __ffsll((unsigned long long)bal) - 1);
                 bal &= bal - 1;
                 PathRef pq = load_path(c, q);
                 for (;;) {
                     const bool more = bal != 0;
-                    const int qn = more ? cbase + __ffsll((unsigned long long)bal) - 1 : q;
+                    const int qn = more ? __builtin_amdgcn_readlane(myq, __ffsll((unsigned long long)bal) - 1) : q;
                     bal &= bal - 1;
                     const PathRef pn = load_path(c, qn);                          // in flight while this route is processed
                     uint64_t x = row_of(path_free_ext(c, pq));

@@ -232,6 +232,35 @@ def test_randomised_configurations_vs_oracle(case, generic, monkeypatch):
     assert got["terminated"].sum() >= 2 * B
 
 
+@pytest.mark.parametrize("pid", list(range(1, 12)))
+@pytest.mark.parametrize("case", range(2))
+def test_policies_randomised_configurations_vs_oracle(pid, case):
+    """Every fused policy other than first fit (ids 1..11) on two randomly drawn configurations each, after a first-fit
+    warm-up: step records and grids equal to the oracle's."""
+    rng = np.random.default_rng(7000 + 31 * pid + case)
+    topo = ["nsfnet", "cost239", "ring4"][int(rng.integers(0, 3))]
+    tb = golden_tables(topo)
+    k = int(rng.integers(2, tb.k_paths + 1))
+    if k < tb.k_paths:
+        tb = tb.truncated(k)
+    S = int(rng.integers(48, 140 if pid >= 10 else 300))
+    rates = tuple(int(x) for x in np.sort(rng.choice(np.array([10, 40, 100, 200, 400]), size=int(rng.integers(2, 5)), replace=False)))
+    B, warm, steps = 4, int(rng.integers(100, 300)), 90 if pid >= 10 else 260
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=S, capacity=512, load=float(rng.uniform(90, 220) * S / 100),
+              bit_rate_selection="discrete", bit_rates=rates, auto_reset=True, episode_length=1000,
+              launch_power_dbm=float(rng.uniform(-2, 3)), margin=float(rng.choice([0.0, 0.5])))
+    holder = nat.ConfigHolder(tb, batch=B, **kw)
+    env = BatchedQRMSAEnv(tables=tb, batch_size=B, **kw)
+    env.seed(3 + case); env.reset()
+    env.step_policy(warm, record=False)
+    got = env.step_policy(steps, policy=pid)
+    for r in range(B):
+        o = OracleEnv(holder, replica=r)
+        o.seed(3 + case); o.reset(); o.run_policy(0, warm)
+        assert_records_equal(got[:, r], o.run_policy(pid, steps), f"policy {pid} case {case}: {topo} S={S} k={k} rates={rates} replica {r}")
+        np.testing.assert_array_equal(env.grid(r), o.grid())
+
+
 def test_sharded_batch_equals_unsharded_bit_exact():
     """A batch split over two environments with replica bases 0 and B/2 (what two ranks of bench.py / a sharded sweep
     own, `shard_bounds`) reproduces the single environment of B replicas bit for bit: per-replica statistics, grids and
