@@ -261,6 +261,56 @@ def test_policies_randomised_configurations_vs_oracle(pid, case):
         np.testing.assert_array_equal(env.grid(r), o.grid())
 
 
+@pytest.mark.parametrize("case", range(6))
+def test_random_external_actions_vs_oracle(case):
+    """env.step(actions) with a mix of the first-fit action, the reject action and actions drawn uniformly from the whole
+    codec (most decode to occupied slots: the penalty of quirk Q5, some to a QoT failure: flagged, nothing applied, the
+    oracle's step returns its error code there) on random configurations; every record, then grids and services."""
+    rng = np.random.default_rng(4000 + case)
+    topo = ["nsfnet", "cost239", "nobel-eu"][int(rng.integers(0, 3))]
+    tb = golden_tables(topo)
+    S = int(rng.integers(48, 200))
+    rates = tuple(int(x) for x in np.sort(rng.choice(np.array([10, 40, 100, 200, 400]), size=3, replace=False)))
+    B, warm, steps = 5, 200, 220
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=S, capacity=512, load=float(rng.uniform(120, 260) * S / 100),
+              bit_rate_selection="discrete", bit_rates=rates, auto_reset=False, episode_length=10 ** 6,
+              launch_power_dbm=float(rng.uniform(-2, 2)), margin=0.0)
+    holder = nat.ConfigHolder(tb, batch=B, **kw)
+    env = BatchedQRMSAEnv(tables=tb, batch_size=B, **kw)
+    env.seed(5 + case); env.reset()
+    env.step_policy(warm, record=False)
+    oracles = []
+    for r in range(B):
+        o = OracleEnv(holder, replica=r)
+        o.seed(5 + case); o.reset(); o.run_first_fit(warm)
+        oracles.append(o)
+    kinds = np.zeros(4, int)
+    for i in range(steps):
+        ff, _ = env.policy_actions()
+        u = rng.random(B)
+        acts = np.where(u < 0.5, ff, np.where(u < 0.65, env.reject_action, rng.integers(0, env.reject_action + 1, B))).astype(np.int32)
+        rec = env.step(acts)
+        for r, o in enumerate(oracles):
+            rc, want = o.step(int(acts[r]))
+            got = rec[r]
+            if rc != 0:                                           # the reference raises its QoT ValueError here
+                assert got["flags"] & nat.F_QOT_ERROR and not got["accepted"], (i, r)
+                kinds[3] += 1
+                continue
+            assert not (got["flags"] & nat.F_QOT_ERROR), (i, r)
+            for f in ("action", "accepted", "retry", "route", "slot", "modulation", "nslots", "reward", "terminated", "active"):
+                assert got[f] == want[f], (i, r, f, got[f], want[f])
+            if got["accepted"]:
+                np.testing.assert_allclose(got["osnr"], want["osnr"], rtol=GSNR_RTOL)
+            kinds[0 if got["accepted"] else (1 if got["retry"] else 2)] += 1
+    for r, o in enumerate(oracles):
+        np.testing.assert_array_equal(env.grid(r), o.grid())
+        a = np.sort(env.services(r), order=["release_time", "path_id", "slot"])
+        b = np.sort(o.services(), order=["release_time", "path_id", "slot"])
+        assert a.tobytes() == b.tobytes()
+    assert kinds[0] > 100 and kinds[1] > 50 and kinds[2] > 50, kinds      # accepted, occupied-slot retries, rejections
+
+
 def test_sharded_batch_equals_unsharded_bit_exact():
     """A batch split over two environments with replica bases 0 and B/2 (what two ranks of bench.py / a sharded sweep
     own, `shard_bounds`) reproduces the single environment of B replicas bit for bit: per-replica statistics, grids and
