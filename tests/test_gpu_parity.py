@@ -311,6 +311,51 @@ def test_random_external_actions_vs_oracle(case):
     assert kinds[0] > 100 and kinds[1] > 50 and kinds[2] > 50, kinds      # accepted, occupied-slot retries, rejections
 
 
+@pytest.mark.parametrize("feature", ["defragmentation", "measure_disruptions", "track_service_ids"])
+@pytest.mark.parametrize("case", range(3))
+def test_stateful_features_randomised_configurations_vs_oracle(feature, case):
+    """defragmentation (random n_defrag_services), measure_disruptions and service-id tracking with a counters-only reset in
+    the middle, each on three randomly drawn configurations: records, counters, grids and running services vs the oracle."""
+    rng = np.random.default_rng(9000 + 17 * case + len(feature))
+    topo = ["nsfnet", "cost239", "nobel-eu"][int(rng.integers(0, 3))]
+    tb = golden_tables(topo)
+    S = int(rng.integers(64, 260))
+    rates = tuple(int(x) for x in np.sort(rng.choice(np.array([10, 40, 100, 200, 400]), size=3, replace=False)))
+    B, steps = 5, 520
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=S, capacity=512, load=float(rng.uniform(110, 230) * S / 100),
+              bit_rate_selection="discrete", bit_rates=rates, auto_reset=True, episode_length=int(rng.integers(180, 400)),
+              launch_power_dbm=float(rng.uniform(-2, 3)), margin=float(rng.choice([0.0, 0.5])))
+    if feature == "defragmentation":
+        kw.update(defragmentation=True, n_defrag_services=int(rng.integers(0, 8)))
+    elif feature == "measure_disruptions":
+        kw.update(measure_disruptions=True)
+    else:
+        kw.update(track_service_ids=True)
+    holder = nat.ConfigHolder(tb, batch=B, **kw)
+    env = BatchedQRMSAEnv(tables=tb, batch_size=B, **kw)
+    env.seed(21 + case); env.reset()
+    half = steps // 2
+    got1 = env.step_policy(half)
+    if feature == "track_service_ids":
+        env.reset_episode_counters()
+    got2 = env.step_policy(steps - half)
+    st = env.stats()
+    for r in range(B):
+        o = OracleEnv(holder, replica=r)
+        o.seed(21 + case); o.reset()
+        want1 = o.run_first_fit(half)
+        if feature == "track_service_ids":
+            o.reset_counters()
+        want2 = o.run_first_fit(steps - half)
+        assert_records_equal(got1[:, r], want1, f"{feature} case {case} {topo} S={S} replica {r} (first half)")
+        assert_records_equal(got2[:, r], want2, f"{feature} case {case} {topo} S={S} replica {r} (second half)")
+        so = o.stats()
+        for f in ("services_accepted", "episodes_completed", "active", "disrupted_services", "episode_disrupted_services",
+                  "episode_defrag_cycles", "episode_service_reallocations", "episode_services_processed", "rejected"):
+            assert st[r][f] == so[f], (feature, case, r, f, st[r][f], so[f])
+        np.testing.assert_array_equal(env.grid(r), o.grid())
+
+
 def test_sharded_batch_equals_unsharded_bit_exact():
     """A batch split over two environments with replica bases 0 and B/2 (what two ranks of bench.py / a sharded sweep
     own, `shard_bounds`) reproduces the single environment of B replicas bit for bit: per-replica statistics, grids and
