@@ -233,17 +233,19 @@ def test_randomised_configurations_vs_oracle(case, generic, monkeypatch):
 
 
 @pytest.mark.parametrize("pid", list(range(1, 12)))
-@pytest.mark.parametrize("case", range(2))
+@pytest.mark.parametrize("case", range(3))
 def test_policies_randomised_configurations_vs_oracle(pid, case):
     """Every fused policy other than first fit (ids 1..11) on two randomly drawn configurations each, after a first-fit
     warm-up: step records and grids equal to the oracle's."""
     rng = np.random.default_rng(7000 + 31 * pid + case)
     topo = ["nsfnet", "cost239", "ring4"][int(rng.integers(0, 3))]
+    if case == 2:
+        topo = "nobel-eu"            # 41 links: the generic record codec (no link mask in the record)
     tb = golden_tables(topo)
     k = int(rng.integers(2, tb.k_paths + 1))
     if k < tb.k_paths:
         tb = tb.truncated(k)
-    S = int(rng.integers(48, 140 if pid >= 10 else 300))
+    S = int(rng.integers(48, (100 if topo == "nobel-eu" else 140) if pid >= 10 else 300))
     rates = tuple(int(x) for x in np.sort(rng.choice(np.array([10, 40, 100, 200, 400]), size=int(rng.integers(2, 5)), replace=False)))
     B, warm, steps = 4, int(rng.integers(100, 300)), 90 if pid >= 10 else 260
     kw = dict(modulations=jocn_modulations(), num_spectrum_resources=S, capacity=512, load=float(rng.uniform(90, 220) * S / 100),
