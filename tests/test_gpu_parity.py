@@ -358,6 +358,42 @@ def test_stateful_features_randomised_configurations_vs_oracle(feature, case):
         np.testing.assert_array_equal(env.grid(r), o.grid())
 
 
+@pytest.mark.parametrize("kind", ["continuous", "per_link_alpha", "germany50"])
+@pytest.mark.parametrize("case", range(2))
+def test_generic_kernel_configurations_randomised_vs_oracle(kind, case):
+    """What only the generic k_run serves - continuous bit rates (random bounds), per-link attenuation, a topology with more
+    than 52 links - on random configurations: fused first fit + step vs the oracle."""
+    import copy
+    rng = np.random.default_rng(12000 + 7 * case + len(kind))
+    topo = "germany50" if kind == "germany50" else ["nsfnet", "cost239", "nobel-eu"][int(rng.integers(0, 3))]
+    tb = golden_tables(topo)
+    S = int(rng.integers(64, 300))
+    B, steps = 5, 600
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=S, capacity=512, load=float(rng.uniform(100, 220) * S / 100),
+              auto_reset=True, episode_length=int(rng.integers(200, 400)), launch_power_dbm=float(rng.uniform(-2, 3)),
+              margin=float(rng.choice([0.0, 0.5])))
+    if kind == "continuous":
+        lo = int(rng.integers(10, 120))
+        kw.update(bit_rate_selection="continuous", bit_rates=(10, 40, 100), bit_rate_lower_bound=lo,
+                  bit_rate_higher_bound=lo + int(rng.integers(5, 300)))
+    else:
+        kw.update(bit_rate_selection="discrete",
+                  bit_rates=tuple(int(x) for x in np.sort(rng.choice(np.array([10, 40, 100, 200, 400]), size=3, replace=False))))
+    if kind == "per_link_alpha":
+        tb = copy.deepcopy(tb)
+        tb.link_alpha = tb.link_alpha * rng.uniform(0.85, 1.25, tb.n_links)
+    holder = nat.ConfigHolder(tb, batch=B, **kw)
+    env = BatchedQRMSAEnv(tables=tb, batch_size=B, **kw)
+    env.seed(40 + case); env.reset()
+    assert not env.occupancy()["lean_kernel"]
+    got = env.step_policy(steps)
+    for r in range(B):
+        o = OracleEnv(holder, replica=r)
+        o.seed(40 + case); o.reset()
+        assert_records_equal(got[:, r], o.run_first_fit(steps), f"{kind} case {case}: {topo} S={S} replica {r}")
+        np.testing.assert_array_equal(env.grid(r), o.grid())
+
+
 def test_sharded_batch_equals_unsharded_bit_exact():
     """A batch split over two environments with replica bases 0 and B/2 (what two ranks of bench.py / a sharded sweep
     own, `shard_bounds`) reproduces the single environment of B replicas bit for bit: per-replica statistics, grids and
