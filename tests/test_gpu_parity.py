@@ -394,6 +394,51 @@ def test_generic_kernel_configurations_randomised_vs_oracle(kind, case):
         np.testing.assert_array_equal(env.grid(r), o.grid())
 
 
+@pytest.mark.parametrize("on_table", [True, False], ids=["table_bit_rates", "other_bit_rates"])
+@pytest.mark.parametrize("case", range(3))
+def test_random_request_traces_vs_oracle(case, on_table):
+    """Trace replay (ongym_set_requests): per-replica request traces written on the host - exponential arrivals and holding
+    times rounded to float32, uniform node pairs, bit rates from the configured table (the lean kernel replays those) or
+    arbitrary ones (generic kernel, slot counts by ceil) - stepped through the fused first fit against the oracle on the same
+    traces, to the end of the trace (the steps after it are flagged no-ops)."""
+    from optical_networking_gym._native import REQUEST_DTYPE
+    rng = np.random.default_rng(15000 + case + (50 if on_table else 0))
+    topo = ["nsfnet", "cost239", "nobel-eu"][int(rng.integers(0, 3))]
+    tb = golden_tables(topo)
+    S = int(rng.integers(64, 280))
+    table = (10, 40, 100, 400)
+    B, n = 4, 500
+    load = float(rng.uniform(100, 220) * S / 100)
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=S, capacity=512, load=load, bit_rate_selection="discrete",
+              bit_rates=table, auto_reset=True, episode_length=int(rng.integers(150, 300)),
+              launch_power_dbm=float(rng.uniform(-2, 2)), margin=0.0)
+    reqs = np.zeros((B, n), REQUEST_DTYPE)
+    for r in range(B):
+        at = np.cumsum(rng.exponential(10800.0 / load, n)).astype(np.float32)
+        reqs[r]["arrival_time"] = at
+        reqs[r]["holding_time"] = rng.exponential(10800.0, n).astype(np.float32)
+        src = rng.integers(0, tb.n_nodes, n)
+        dst = (src + rng.integers(1, tb.n_nodes, n)) % tb.n_nodes
+        reqs[r]["source"], reqs[r]["destination"] = src, dst
+        reqs[r]["bit_rate"] = rng.choice(np.array(table), n) if on_table else rng.integers(5, 500, n)
+    holder = nat.ConfigHolder(tb, batch=B, **kw)
+    env = BatchedQRMSAEnv(tables=tb, batch_size=B, **kw)
+    env.set_requests(reqs); env.reset()
+    assert env.occupancy()["lean_kernel"] == on_table
+    got = env.step_policy(n + 5)
+    for r in range(B):
+        # every reset() draws a request of its own (the one drawn by the terminal step is dropped, qrmsa.pyx:427-504): the
+        # trace ends a few steps before n; from there on the device's steps are flagged no-ops
+        noop = (got[:, r]["flags"] & nat.F_NO_REQUEST) != 0
+        valid = int(np.argmax(noop))
+        assert noop[valid:].all() and n - 6 <= valid <= n
+        o = OracleEnv(holder, replica=r)
+        o.set_trace(reqs[r]); o.reset()
+        want = o.run_first_fit(valid)
+        assert_records_equal(got[:valid, r], want, f"trace case {case} {topo} S={S} on_table={on_table} replica {r}")
+        assert int(want["terminated"].sum()) == n - valid - 0 or int(want["terminated"].sum()) == n - valid - 1
+
+
 def test_sharded_batch_equals_unsharded_bit_exact():
     """A batch split over two environments with replica bases 0 and B/2 (what two ranks of bench.py / a sharded sweep
     own, `shard_bounds`) reproduces the single environment of B replicas bit for bit: per-replica statistics, grids and
