@@ -1863,16 +1863,16 @@ __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, ui
             sb = sqrt(fmax(len2 / nb - bm * bm, 0.0)) / 100.0;
         }
         const float f_free = (float)(2.0 * ((double)tot - 0.5 * Sd) / Sd), f_free2 = (float)(2.0 * (((double)tot / Sd) - 0.5));
+        // the wave-uniform sums of format mi are parked in lane mi; the 12 features of all formats are then finished in ONE
+        // pass (lane = format) instead of once per format on 64 identical lanes
+        int r_cnt = 0, r_smax = 0, r_n = -1;
+        double r_ssum = 0.0, r_ssum2 = 0.0, r_osum = 0.0, r_osum2 = 0.0, r_omax = 0.0;
         for (int mi = 0; mi < M; mi++) {
             const int m = mod_start + M - 1 - mi;
             const int fi = Mall - 1 - m;
             const int n = uniform_i32(c.nreq[m]);
-            float *f12 = frow + mi * 12;
             uint8_t *mm = mrow + (long long)mi * S;        // zero-filled by the host before the launch
-            if (n <= 0 || n > S) {
-                if (c.lane == 0) for (int q = 0; q < 12; q++) f12[q] = (q == 4 || q == 10) ? (float)(2.0 * ((double)tot / S - 0.5)) : 0.f;
-                continue;
-            }
+            if (n <= 0 || n > S) continue;                 // lane mi keeps r_n = -1: only the two path-level features are set
             const double thr = P.mod_thr[m], bw = P.slot_bw * n, inv_thr = 1.0 / fabs(thr);
             const double self = path_self_term<UNIFORM_ALPHA>(c, p, n), nlic = G(P.nli_coef)[n] * c.rp[1];
             // the valid starts of _get_candidates (:590), compacted: ascending slot indices in xlist (free again after the
@@ -1912,24 +1912,32 @@ __device__ __forceinline__ void observe_env(Ctx &c, double *Fx, uint64_t *Vw, ui
             const double ssum = (double)wave_sum_i32(sum_l), ssum2 = (double)wave_sum_i32(sum2_l);
             const double osum = wave_sum(os_l), osum2 = wave_sum(os2_l), omax = wave_max_f64(omax_l);
             STAMPW(c, 12);
-            double mean_s = 0.0, std_s = 0.0, om = 0.0, ov = 0.0, best = 0.0;
-            if (cnt > 0) {
-                const double inv_cnt = 1.0 / (double)cnt;
-                mean_s = ssum * inv_cnt;
-                std_s = sqrt(fmax(ssum2 * inv_cnt - mean_s * mean_s, 0.0));
-                om = osum * inv_cnt;
-                ov = fmax(osum2 * inv_cnt - om * om, 0.0);
-                best = fmax(omax, 0.0);                                  // osnr_best starts at 0.0 (:604,622)
+            if (c.lane == mi) {
+                r_cnt = cnt; r_smax = smax; r_n = n;
+                r_ssum = ssum; r_ssum2 = ssum2; r_osum = osum; r_osum2 = osum2; r_omax = omax;
             }
-            const double adj = ((double)n - 5.5) / 3.5;
-            // lane q stores feature q (one store instruction); a select chain, not a divergent switch
-            const float fv[12] = {(float)((double)cnt * inv_S), (float)(mean_s * inv_S1), (float)(std_s * inv_S1),
-                                  (float)(adj > 0.0 ? adj : 0.0), f_free, (float)mb, (float)sb, (float)best, (float)om, (float)ov,
-                                  f_free2, (float)((double)smax * inv_S1)};
-            float v = fv[0];
+        }
+        {
+            double mean_s = 0.0, std_s = 0.0, om = 0.0, ov = 0.0, best = 0.0;
+            if (r_cnt > 0) {
+                const double inv_cnt = 1.0 / (double)r_cnt;
+                mean_s = r_ssum * inv_cnt;
+                std_s = sqrt(fmax(r_ssum2 * inv_cnt - mean_s * mean_s, 0.0));
+                om = r_osum * inv_cnt;
+                ov = fmax(r_osum2 * inv_cnt - om * om, 0.0);
+                best = fmax(r_omax, 0.0);                                // osnr_best starts at 0.0 (:604,622)
+            }
+            const double adj = ((double)r_n - 5.5) / 3.5;
+            const bool real = r_n > 0;                                   // a format whose slot count does not fit: zeros but 4, 10
+            const float fv[12] = {real ? (float)((double)r_cnt * inv_S) : 0.f, real ? (float)(mean_s * inv_S1) : 0.f,
+                                  real ? (float)(std_s * inv_S1) : 0.f, real ? (float)(adj > 0.0 ? adj : 0.0) : 0.f,
+                                  real ? f_free : f_free2, real ? (float)mb : 0.f, real ? (float)sb : 0.f,
+                                  real ? (float)best : 0.f, real ? (float)om : 0.f, real ? (float)ov : 0.f, f_free2,
+                                  real ? (float)((double)r_smax * inv_S1) : 0.f};
+            if (c.lane < M) {
 #pragma unroll
-            for (int q = 1; q < 12; q++) v = c.lane == q ? fv[q] : v;
-            if (c.lane < 12) f12[c.lane] = v;
+                for (int q = 0; q < 12; q++) frow[c.lane * 12 + q] = fv[q];
+            }
             STAMPW(c, 13);
         }
     }

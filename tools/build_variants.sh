@@ -9,7 +9,7 @@ for spec in "$@"; do
   name=${spec%%:*}; flags=""; [[ "$spec" == *:* ]] && flags=${spec#*:}
   if [ "$name" == "head" ]; then
     T=$(mktemp -d); mkdir -p $T/optical-networking-gym_amd/csrc $T/include
-    for f in ongym_hip.hip ongym_device.hpp ongym_fast.hpp; do git -C $REPO show HEAD:optical-networking-gym_amd/csrc/$f > $T/optical-networking-gym_amd/csrc/$f; done
+    for f in ongym_hip.hip $(cd $CSRC && ls *.hpp); do git -C $REPO show HEAD:optical-networking-gym_amd/csrc/$f > $T/optical-networking-gym_amd/csrc/$f; done
     for f in ongym.h ongym_traffic.h; do git -C $REPO show HEAD:include/$f > $T/include/$f; done
     SRC=$T/optical-networking-gym_amd/csrc/ongym_hip.hip
   else
