@@ -299,6 +299,10 @@ int ongym_stats_get(ongym_env *env, ongym_stats *out);
  * ongym_step_policy(ONGYM_POLICY_FIRST_FIT) launches on this environment, its dynamic LDS bytes per replica, and whether it
  * is the lean kernel (1) or the generic one (0). */
 int ongym_query_occupancy(ongym_env *env, int32_t *blocks_per_cu, int32_t *lds_bytes, int32_t *lean_kernel);
+/* The same for the kernel ongym_step_policy(policy) launches.  Lean kernels (csrc/ongym_fast.hpp) exist for first fit, load
+ * balancing, highest SNR and lowest fragmentation - the four heuristics the reference benchmark selects among
+ * (examples/JOCN_Benchmark_2024/graph_load.py:116-125). */
+int ongym_query_occupancy_policy(ongym_env *env, int32_t policy, int32_t *blocks_per_cu, int32_t *lds_bytes, int32_t *lean_kernel);
 int ongym_sync(ongym_env *env);
 /* Device time (ms, HIP events on the env's stream) of the most recent step launch; <0 if none. */
 double ongym_last_kernel_ms(ongym_env *env);

@@ -61,13 +61,23 @@ __device__ __forceinline__ const __attribute__((address_space(4))) T *KC(const T
     return (const __attribute__((address_space(4))) T *)p;
 }
 
-__host__ __device__ inline size_t fast_lds_bytes(int n_links, int row_words, int capacity, bool m64) {
+__host__ __device__ inline bool fast_policy_has_xlist(int policy) {
+    return policy == ONGYM_POLICY_HIGHEST_SNR || policy == ONGYM_POLICY_LOWEST_FRAGMENTATION;
+}
+__host__ __device__ inline size_t fast_lds_bytes(int n_links, int row_words, int capacity, bool m64, int n_slots = 0,
+                                                 int policy = ONGYM_POLICY_FIRST_FIT) {
     size_t b = ((size_t)n_links * row_words * 8 + 15) & ~(size_t)15;   // occ  u32 [E][2W]
     b += (size_t)(n_links + 1) * 16 + 64;                               // lw (w1,w2) [E + a zero entry] | phi [8]
     b += (size_t)(capacity + 1) * 8 + (m64 ? (size_t)(capacity + 1) * 4 : 0);   // rec {a,b} | (a2), + one neutral entry
     b += (size_t)capacity * (4 + 2);                                    // rr | list
     b += 48;                                                            // cold wave-uniform state (5 doubles)
-    return (b + 15) & ~(size_t)15;
+    b = (b + 15) & ~(size_t)15;
+    if (fast_policy_has_xlist(policy)) {
+        b += ((size_t)(n_slots + 1) * 2 + 15) & ~(size_t)15;            // xlist: candidate starts, compacted
+        b += 64 * (8 + 16);                                             // stage: 64 interferers {centre, row} | {w1, Phi w2}
+    }
+    if (policy == ONGYM_POLICY_LOWEST_FRAGMENTATION) b += ((size_t)(n_slots + 1) * 8 + 15) & ~(size_t)15;   // plogp table
+    return b;
 }
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
@@ -90,6 +100,11 @@ __device__ __forceinline__ uint32_t run_and32(uint32_t x, int &r, int m) {
         r += s;
     }
     return x;
+}
+
+__device__ __forceinline__ double wave_min_f64(double v) {     // as wave_max_f64 (ongym_device.hpp); wave-uniform result
+    v = fmin(v, dpp_f64<0xB1>(v)); v = fmin(v, dpp_f64<0x4E>(v)); v = fmin(v, dpp_f64<0x141>(v)); v = fmin(v, dpp_f64<0x140>(v));
+    return fmin(fmin(readlane_f64(v, 0), readlane_f64(v, 16)), fmin(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 
 __device__ __forceinline__ int first_set32(uint32_t x) {
@@ -190,7 +205,7 @@ __device__ __forceinline__ void fast_refill_trace(const Params &P, int replica, 
     }
 }
 
-template <bool M64, bool REC, int ENT, bool TRACE>
+template <bool M64, bool REC, int ENT, bool TRACE, int POL = ONGYM_POLICY_FIRST_FIT>
 __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step_rec *out, unsigned char *smem) {
     ONGYM_NO_CONTRACT
 #ifdef ONGYM_STAMPS
@@ -216,6 +231,12 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
     // [0] bit_rate_requested [1] bit_rate_provisioned [2] episode_bit_rate_requested [3] episode_bit_rate_provisioned at the
     // start of the launch / episode (the launch adds counts x bit rate), [4] osnr_flushed
     double *const cold = reinterpret_cast<double *>(smem + ((o + 7) & ~(size_t)7));
+    // only with fast_policy_has_xlist: xlist u16[S+1] | st_ck uint2[64] | st_w double2[64] | (LOWEST_FRAGMENTATION) plt f64[S+1]
+    const size_t o_x = fast_lds_bytes(E, P.row_words, C, M64);
+    uint16_t *const xlist = reinterpret_cast<uint16_t *>(smem + o_x);
+    uint2 *const st_ck = reinterpret_cast<uint2 *>(smem + o_x + (((size_t)(S + 1) * 2 + 15) & ~(size_t)15));
+    double2 *const st_w = reinterpret_cast<double2 *>(st_ck + 64);
+    double *const plt = reinterpret_cast<double *>(st_w + 64);
     const uint32_t occ_base = lds_addr(occ), rec_base = lds_addr(rec), rr_base = lds_addr(rr), a2_base = lds_addr(a2);
     // A zero the compiler cannot see through.  Wave-uniform integer arithmetic that only feeds LDS addresses and data is cheaper
     // on the vector pipe (2.5 cycles per instruction, ~60 % busy) than on the scalar pipe (4.3 cycles, ~70 % busy, and its
@@ -226,6 +247,8 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
     // ---- load: constants, bitmap, records (generic codec -> lean codec) ----
     for (int i = lane; i <= E; i += kWave) { lw[2 * i] = i < E ? G(P.link_w1)[i] : 0.0; lw[2 * i + 1] = i < E ? G(P.link_w2)[i] : 0.0; }
     if (lane < kMaxMods) phi[lane] = lane < M ? P.mod_phi53[lane] : 0.0;
+    if (POL == ONGYM_POLICY_LOWEST_FRAGMENTATION)
+        for (int i = lane; i <= S; i += kWave) plt[i] = G(P.plogp)[i];
     {
         const uint32_t *g = reinterpret_cast<const uint32_t *>(P.occ + (size_t)replica * E * P.row_words);
         for (int i = lane; i < E * RW; i += kWave) occ[i] = g[i];
@@ -259,8 +282,9 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
     // ---- per-lane tables: lane q = 8*bit_rate_index + modulation ----
     const double lp = uniform_f64(ge->launch_power), margin = uniform_f64(ge->margin);
     const double rp0 = 1.0 / lp, lp2 = lp * lp;
-    int t_n;
+    int t_n, t1_n = 0;
     double t_nlic, t_selfa, t_lim_lo, t_lim_hi;
+    double t1_nlic = 0.0, t1_selfa = 0.0, t1_lim_lo = -1.0, t1_lim_hi = -1.0;
     {
         const int qb = lane >> 3, qm = lane & 7;
         const bool valid = qb < P.n_bit_rates && qm < M;
@@ -273,7 +297,21 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         const bool usable = valid && t_n >= 1 && t_n <= S;
         t_lim_lo = usable ? lim * (1.0 - 1e-9) : -1.0;
         t_lim_hi = usable ? lim * (1.0 + 1e-9) : -1.0;
+        // LOWEST_FRAGMENTATION searches (and evaluates) at slots + 1 (heuristics.py:357): the same tables one slot wider
+        if (POL == ONGYM_POLICY_LOWEST_FRAGMENTATION) {
+            const bool usable1 = valid && t_n >= 1 && t_n + 1 <= S;
+            t1_n = valid ? t_n + 1 : 0;
+            t1_nlic = usable1 ? G(P.nli_coef)[t_n + 1] * lp2 : 0.0;
+            t1_selfa = usable1 ? G(P.self_asinh)[t_n + 1] : 0.0;
+            t1_lim_lo = usable1 ? lim * (1.0 - 1e-9) : -1.0;
+            t1_lim_hi = usable1 ? lim * (1.0 + 1e-9) : -1.0;
+        }
     }
+    // the tables the policy's search uses
+    constexpr bool kLF = POL == ONGYM_POLICY_LOWEST_FRAGMENTATION;
+    const int &w_n = kLF ? t1_n : t_n;
+    const double &w_nlic = kLF ? t1_nlic : t_nlic, &w_selfa = kLF ? t1_selfa : t_selfa;
+    const double &w_lim_lo = kLF ? t1_lim_lo : t_lim_lo, &w_lim_hi = kLF ? t1_lim_hi : t_lim_hi;
 
     // ---- wave-uniform state from DevEnv ----
     uint64_t req_base = readlane_u64(ge->req_index, 0);        // ring lane i = request req_base + i
@@ -423,6 +461,53 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
 
     const char __attribute__((address_space(1))) *const tab = (const char __attribute__((address_space(1))) *)P.pair_tab2k;
 
+    // LOWEST_FRAGMENTATION: score of a route = 0.33 * mean link entropy + 0.33 * cuts + 0.34 * rss over the route's link rows
+    // (heuristics.py:375-384, utils.pyx:61-107), bit for bit — see lf_route_score (ongym_scored.hpp) for why that is possible;
+    // this is the same walk on 32-bit words.  Lane h walks the OCCUPIED runs of the route's h-th link (the trial allocation
+    // paints free slots free: the score does not depend on the candidate); the entropies are added in the order of path.links.
+    auto route_score = [&](int path, int hops) -> double {
+        double ent = 0.0, sq = 0.0, sl = 0.0;
+        int cuts = 0;
+        if (lane < hops) {
+            const uint32_t *row = occ + (size_t)G(P.path_links)[path * P.max_hops + lane] * RW;
+            int carry = 0;                                   // length of the run that is open at the current position
+            auto close = [&](int len) {
+                ent += plt[len];                             // entropy += p * math.log(p) (Params.plogp, copied to LDS)
+                cuts++;
+                sq += (double)len * (double)len;
+                sl += (double)len;
+            };
+            for (int w = 0; w < RW; w++) {
+                const int nb = min(32, S - 32 * w);
+                if (nb <= 0) break;
+                uint32_t z = ~row[w];
+                if (nb < 32) z &= (1u << nb) - 1u;
+                int pos = 0;
+                while (pos < nb) {
+                    const uint32_t rest = z >> pos;
+                    if (carry > 0 || (rest & 1u)) {
+                        const uint32_t inv = ~rest;
+                        int len = inv ? __builtin_ctz(inv) : 32;
+                        len = min(len, nb - pos);
+                        carry += len; pos += len;
+                        if (pos < nb) { if (carry > 0) close(carry); carry = 0; }
+                    } else {
+                        pos += rest ? __builtin_ctz(rest) : 32;
+                    }
+                }
+            }
+            if (carry > 0) close(carry);
+            ent = ent != 0.0 ? -ent : 0.0;                   // utils.pyx:79
+        }
+        double se = 0.0;                                     // sum(entropies): left to right, starting from int 0
+        for (int h = 0; h < hops; h++) se = __dadd_rn(se, readlane_f64(ent, h));
+        se = se / (double)hops;
+        const int tc = wave_sum_i32(cuts);
+        const double tsq = wave_sum(sq), tsl = wave_sum(sl);   // integers < 2^53: exact in any order
+        const double rss = tsl == 0.0 ? 0.0 : sqrt(tsq) / tsl;
+        return uniform_f64(__dadd_rn(__dadd_rn(__dmul_rn(0.33, se), __dmul_rn(0.33, (double)tc)), __dmul_rn(0.34, rss)));
+    };
+
     if (!uniform_i32(ge->have_request)) {            // never reset: every step is a no-op (same as k_run)
         if (lane == 0) {
             ge->st.flags |= ONGYM_F_NO_REQUEST;
@@ -447,175 +532,383 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             }
             continue;
         }
-        // ================= policy: heuristic_shortest_available_path_first_fit_best_modulation =========================
+        // ================= policy (heuristics/heuristics.py) ==========================================================
+        //   FIRST_FIT            :923-966  first (route, best format, lowest start) whose GSNR passes
+        //   LOAD_BALANCING       :547-627  the same search on every route whose load (busy slots per hop) is below the best so far
+        //   HIGHEST_SNR          :272-328  every start of every (route, format): the highest GSNR among those that pass
+        //   LOWEST_FRAGMENTATION :330-414  routes in order of a fragmentation score that is one number per route (quirk, see
+        //                                  ongym_scored.hpp); per route the first start (format high to low, start low to high)
+        //                                  whose GSNR passes at slots + 1
         int ch_k = -1, ch_m = 0, ch_slot = 0, ch_n = 0, ch_path = -1;
         uint64_t ch_mask = 0;
         double ch_acc = 0.0, ch_ase = 0.0, ch_nli = 0.0;
-        for (int k = 0; k < K; k++) {
-            const int path = k == 0 ? cur_p0 : uniform_i32(KC(P.pair_paths)[(cur_src * N + cur_dst) * K + k]);
-            if (path < 0) break;
-            // (fetching the first route's record already when the request is popped was measured 2.4 % SLOWER: eight more
-            //  live SGPRs across the departures scan cost more than the scalar-load latency they hide)
-            const PathRec pr = load_path_rec(path_recs, path);
-            d_paths++; d_hops += pr.hops;
+        double best_acc = INFINITY;                 // HIGHEST_SNR: 1/GSNR of the best candidate so far
+        bool lf_qot = false;
+        // the interferers of ONE route, cached in registers (lane j + 64 e = entry j of the list); `L` = their number
+        uint32_t e_c2k[ENT], e_key4[ENT];
+        double e_w1[ENT], e_pw2[ENT];
+        int e_terms = 0, L = -1, cache_path = -1, cache_terms = 0;
+        double ev_acc = 0.0, ev_ase = 0.0, ev_nli = 0.0;      // results of eval_one for the lane that counts
+
+        // centre, table row, summed link weights (Phi folded in) of running service `idx` as an interferer of the route
+        auto intf_of = [&](int idx, uint32_t mask_lo, uint32_t mask_hi, uint32_t &c2k, uint32_t &key4, double &w1o, double &pw2o) -> int {
+            const uint2 ab = rec[idx];
+            c2k = ab.y & 0x7FFu;
+            key4 = ((ab.y >> 14) & 0x1FFu) << 15;           // (n-1) * kTabPitch entries * 16 bytes
+            uint32_t mm = ab.x & mask_lo;
+            double w1 = 0.0, w2 = 0.0;
+            int terms = __popc(mm);
+            while (mm) { const int l = __ffs(mm) - 1; mm &= mm - 1; w1 += lw[2 * l]; w2 += lw[2 * l + 1]; }
+            if (M64) {
+                uint32_t mh = a2[idx] & mask_hi & 0xFFFFFu;
+                terms += __popc(mh);
+                while (mh) { const int l = 32 + __ffs(mh) - 1; mh &= mh - 1; w1 += lw[2 * l]; w2 += lw[2 * l + 1]; }
+            }
+            w1o = w1;
+            pw2o = phi[(ab.y >> 11) & 7u] * w2;
+            return terms;
+        };
+        // pass 1 of the GN model: interferers of the route -> LDS list -> registers (the first 64*ENT of them)
+        auto build_cache = [&](uint32_t mask_lo, uint32_t mask_hi) {
+            L = 0;
+            for (int base = 0; base < active; base += 2 * kWave) {
+                const int i0 = base + lane, i1 = i0 + kWave;
+                const int i1c = min(i1, C);          // beyond the table: the neutral entry
+                bool ov0 = (rec[i0].x & mask_lo) != 0, ov1 = (rec[i1c].x & mask_lo) != 0;    // unused entries: mask 0
+                if (M64) { ov0 |= (a2[i0] & mask_hi & 0xFFFFFu) != 0; ov1 |= (a2[i1c] & mask_hi & 0xFFFFFu) != 0; }
+                const uint64_t bal0 = __ballot(ov0), bal1 = __ballot(ov1);
+                const int n0 = __popcll((unsigned long long)bal0);
+                const int p0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal0, 0));
+                const int p1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal1, 0));
+                if (ov0) list[L + p0] = (uint16_t)i0;
+                if (ov1) list[L + n0 + p1] = (uint16_t)i1;
+                L += n0 + __popcll((unsigned long long)bal1);
+            }
+            wave_sync();
+            FSTAMP(3);
+            e_terms = 0;
+#pragma unroll
+            for (int e = 0; e < ENT; e++) {
+                const int j = lane + kWave * e;
+                e_c2k[e] = 0; e_key4[e] = 0; e_w1[e] = 0.0; e_pw2[e] = 0.0;
+                if (j < L) e_terms += intf_of(list[j], mask_lo, mask_hi, e_c2k[e], e_key4[e], e_w1[e], e_pw2[e]);
+            }
+            if (POL == ONGYM_POLICY_HIGHEST_SNR || POL == ONGYM_POLICY_LOWEST_FRAGMENTATION) {
+                int tt = e_terms;       // interferer-link terms of one evaluation on this route (statistics)
+                for (int base = kWave * ENT; base < L; base += kWave)
+                    if (base + lane < L) { uint32_t a_, b_; double c_, d_; tt += intf_of(list[base + lane], mask_lo, mask_hi, a_, b_, c_, d_); }
+                cache_terms = wave_sum_i32(tt);
+            }
+        };
+        // pass 2: 1/GSNR of ONE candidate (start `first`, width nn) with lanes over the interferers.  Every lane finishes the
+        // evaluation for ITS (bit rate, format) entry of the per-lane tables l_*; lane q is the one that counts.  Returns
+        // the decision of qot_ok; ev_acc (and ev_ase / ev_nli when records are written) hold lane q's values when it passes.
+        auto eval_one = [&](int first, int nn, int q, const PathRec &pr, double l_bw, double l_h, double l_nlic, double l_selfa,
+                            double l_lo, double l_hi) -> int {
+            const uint32_t c2 = (uint32_t)(2 * first + nn);
+            double part = 0.0;
+            {
+                TabPair t[ENT];
+#pragma unroll
+                for (int e = 0; e < ENT; e++) {
+                    const uint32_t adi = __builtin_amdgcn_sad_u16(e_c2k[e], c2, 0);       // |c2k - c2|, both < 2^11
+                    t[e] = load_pair(tab, e_key4[e] | (adi << 4));
+                }
+#pragma unroll
+                for (int e = 0; e < ENT; e++) part += t[e].x * e_w1[e] - t[e].y * e_pw2[e];
+            }
+            lane_terms += e_terms;
+            for (int base = kWave * ENT; base < L; base += kWave) {       // interferers beyond the register cache
+                const int j = base + lane;
+                if (j < L) {
+                    uint32_t c2k, key4;
+                    double w1, pw2;
+                    lane_terms += intf_of(list[j], pr.mask_lo, pr.mask_hi, c2k, key4, w1, pw2);
+                    const uint32_t adi = __builtin_amdgcn_sad_u16(c2k, c2, 0);
+                    const TabPair t = load_pair(tab, key4 | (adi << 4));
+                    part += t.x * w1 - t.y * pw2;
+                }
+            }
+            d_evals++;
+            const double tot = wave_sum(part);
+            const double fc = P.f0 + (P.slot_bw * first) + l_h;                  // envs/qrmsa.pyx:901-905
+            const double g_nli = l_nlic * (tot + pr.w1 * l_selfa);
+            const double g_ase = (l_bw * fc * pr.ase) * rp0;
+            const double acc = g_ase + g_nli;
+            int ok;
+            {
+                const uint64_t yes = __ballot(acc <= l_lo), no = __ballot(acc >= l_hi);
+                if ((yes >> q) & 1ull) ok = 1;
+                else if ((no >> q) & 1ull) ok = 0;
+                else {      // inside the 1e-9 band: the reference's own dB-domain expression (see qot_ok)
+                    const uint64_t db = __ballot(10.0 * log10(1.0 / acc) >= P.mod_thr[lane & 7] + *KC(&ge->margin));
+                    ok = (int)((db >> q) & 1ull);
+                }
+            }
+            if (ok) {
+                ev_acc = readlane_f64(acc, q);
+                if (REC) { ev_ase = readlane_f64(g_ase, q); ev_nli = readlane_f64(g_nli, q); }
+            }
+            return ok;
+        };
+        // HIGHEST_SNR / LOWEST_FRAGMENTATION: the set bits of `v` (run-AND words, lane w = word w) as ascending slot indices in
+        // dense lanes (xlist); returns their number
+        auto compact_starts = [&](uint32_t v) -> int {
+            int cnt = 0;
+            for (int i = 0; 2 * i < RW; i++) {
+                const uint32_t w0 = rl(v, 2 * i), w1 = rl(v, 2 * i + 1);
+                if (!(w0 | w1)) continue;
+                const int pre = __builtin_amdgcn_mbcnt_hi(w1, __builtin_amdgcn_mbcnt_lo(w0, 0));
+                const uint32_t mine = lane < 32 ? (w0 >> lane) : (w1 >> (lane - 32));
+                if (mine & 1u) xlist[cnt + pre] = (uint16_t)(64 * i + lane);
+                cnt += __popc(w0) + __popc(w1);
+            }
+            wave_sync();
+            return cnt;
+        };
+        // ... and their GN evaluation with LANES OVER THE CANDIDATES (two chunks of 64 per pass).  The route's interferers are
+        // staged in LDS 64 at a time (centre, table row, summed link weights); every lane then reads the same entry (a
+        // broadcast read, no v_readlane and no scalar registers) and each (interferer, chunk) costs |x - c_k|, one address
+        // op, one 16-byte gather and two FMAs, four interferers (eight gathers) in flight.  No validity test: a valid start
+        // never overlaps a running service on a shared link, so |x - c_k| > n_k; dead lanes read table entries that exist.
+        // Partial sums are lower bounds of 1/GSNR (no interferer term is negative, Params.ase_shortcut): a pass stops as soon
+        // as no candidate can stay below the acceptance limit — or, for HIGHEST_SNR, below the best candidate so far.
+        // HIGHEST_SNR keeps the best passing candidate (strictly smaller 1/GSNR: the first maximum wins, heuristics.py:316);
+        // LOWEST_FRAGMENTATION stops at the first that passes.
+        auto eval_cands = [&](int cnt, int nn, int m, int q, const PathRec &pr, int k, int path, uint64_t pmask, double l_nlic,
+                              double l_selfa, double l_lo, double l_hi) -> bool {
+            constexpr int NA = 2, TU = 4;
+            const double c_bw = P.slot_bw * nn, c_h = P.slot_bw * (nn / 2.0);
+            const double c_nlic = readlane_f64(l_nlic, q), c_self = pr.w1 * readlane_f64(l_selfa, q);
+            const double c_lo = readlane_f64(l_lo, q), c_hi = readlane_f64(l_hi, q);
+            for (int j0 = 0; j0 < cnt; j0 += NA * kWave) {
+                const bool two = j0 + kWave < cnt;          // the second chunk holds candidates (wave-uniform)
+                uint32_t ss[NA], xs[NA];
+                double f[NA], gase[NA];
+                bool live[NA];
+#pragma unroll
+                for (int a = 0; a < NA; a++) {
+                    const int j = j0 + a * kWave + lane;
+                    live[a] = j < cnt;
+                    ss[a] = live[a] ? (uint32_t)xlist[j] : 0u;
+                    xs[a] = 2u * ss[a] + (uint32_t)nn;
+                    f[a] = 0.0;
+                    const double fc = P.f0 + (P.slot_bw * (int)ss[a]) + c_h;           // envs/qrmsa.pyx:901-905
+                    gase[a] = (c_bw * fc * pr.ase) * rp0;
+                }
+                const double thr = POL == ONGYM_POLICY_HIGHEST_SNR ? fmin(c_hi, best_acc) : c_hi;
+                bool cut = false;
+                for (int base = 0; base < L && !cut; base += kWave) {
+                    {   // stage: lane j = interferer base + j (zero weights beyond the list)
+                        uint32_t c2k = 0, key4 = 0;
+                        double w1 = 0.0, pw2 = 0.0;
+                        if (base + lane < L) intf_of((int)list[base + lane], pr.mask_lo, pr.mask_hi, c2k, key4, w1, pw2);
+                        st_ck[lane] = make_uint2(c2k, key4);
+                        st_w[lane] = make_double2(w1, pw2);
+                    }
+                    wave_sync();
+                    const int ne = min(kWave, L - base);
+                    for (int t = 0; t < ne; t += TU) {
+                        uint2 ck[TU];
+                        double2 w[TU];
+#pragma unroll
+                        for (int u = 0; u < TU; u++) { ck[u] = st_ck[t + u]; w[u] = st_w[t + u]; }
+                        TabPair tp[TU][NA];
+#pragma unroll
+                        for (int u = 0; u < TU; u++)
+#pragma unroll
+                            for (int a = 0; a < NA; a++)
+                                if (a == 0 || two) tp[u][a] = load_pair(tab, ck[u].y | (__builtin_amdgcn_sad_u16(xs[a], ck[u].x, 0) << 4));
+#pragma unroll
+                        for (int u = 0; u < TU; u++)
+#pragma unroll
+                            for (int a = 0; a < NA; a++)
+                                if (a == 0 || two) f[a] += tp[u][a].x * w[u].x - tp[u][a].y * w[u].y;
+                        if ((t & 15) == 12 && base + t + TU < L) {      // every 16 interferers: can any candidate still matter?
+                            bool alive = live[0] && gase[0] + c_nlic * (f[0] + c_self) < thr;
+                            if (two) alive |= live[1] && gase[1] + c_nlic * (f[1] + c_self) < thr;
+                            if (!__ballot(alive)) { cut = true; break; }
+                        }
+                    }
+                    wave_sync();                            // the stage is rewritten by the next block
+                }
+#pragma unroll
+                for (int a = 0; a < NA; a++) {
+                    if (a > 0 && !two) break;
+                    d_evals += __popcll((unsigned long long)__ballot(live[a]));
+                    lane_terms += live[a] ? cache_terms : 0;
+                    if (cut) continue;
+                    const double g_nli = c_nlic * (f[a] + c_self);
+                    const double acc = gase[a] + g_nli;
+                    bool ok = live[a] && acc <= c_lo;
+                    if (live[a] && !ok && acc < c_hi) ok = 10.0 * log10(1.0 / acc) >= P.mod_thr[m] + margin;   // the 1e-9 band (qot_ok)
+                    const uint64_t okb = __ballot(ok);
+                    if (!okb) continue;
+                    if (POL == ONGYM_POLICY_HIGHEST_SNR) {
+                        const double v = ok ? acc : INFINITY;
+                        const double vmin = wave_min_f64(v);
+                        if (vmin < best_acc) {
+                            const int ln = __builtin_ctzll(__ballot(v == vmin));
+                            best_acc = vmin; ch_acc = vmin;
+                            ch_k = k; ch_m = m; ch_n = nn; ch_path = path; ch_mask = pmask; ch_slot = (int)rl(ss[a], ln);
+                            if (REC) { ch_ase = readlane_f64(gase[a], ln); ch_nli = readlane_f64(g_nli, ln); }
+                        }
+                    } else {
+                        const int ln = __builtin_ctzll(okb);
+                        ch_k = k; ch_m = m; ch_n = nn - 1; ch_path = path; ch_mask = pmask; ch_slot = (int)rl(ss[a], ln);
+                        return true;
+                    }
+                }
+            }
+            return false;
+        };
+
+        // The routes of the request.  FIRST_FIT walks them in order and stops at the first that serves the request; the other
+        // policies look at all of them, so their ids and records are fetched together (lane k = k-th route).
+        int v_path = -1, v_rank = lane, nk = K;
+        uint32_t v_hops = 1, v_mlo = 0, v_mhi = 0;
+        double v_ase = 0.0, v_w1 = 0.0;
+        if (POL != ONGYM_POLICY_FIRST_FIT) {
+            if (lane < K) {
+                v_path = G(P.pair_paths)[(cur_src * N + cur_dst) * K + lane];
+                if (v_path >= 0) {
+                    const auto *g = G(reinterpret_cast<const PathRec *>(P.path_rec)) + v_path;
+                    v_hops = g->hops; v_mlo = g->mask_lo; v_mhi = g->mask_hi; v_ase = g->ase; v_w1 = g->w1;
+                }
+            }
+            nk = __popcll((unsigned long long)__ballot(v_path >= 0));    // a pair's routes come first, -1 entries after them
+            d_paths += nk;
+        }
+        auto route_rec = [&](int k) -> PathRec {
+            PathRec r;
+            r.id = rl((uint32_t)v_path, k); r.hops = rl(v_hops, k); r.mask_lo = rl(v_mlo, k); r.mask_hi = M64 ? rl(v_mhi, k) : 0u;
+            r.ase = readlane_f64(v_ase, k); r.w1 = readlane_f64(v_w1, k);
+            return r;
+        };
+        auto mask_of = [&](const PathRec &pr) -> uint64_t {
+            return M64 ? ((uint64_t)pr.mask_lo | ((uint64_t)(pr.mask_hi & 0xFFFFFu) << 32)) : (uint64_t)pr.mask_lo;
+        };
+        // LOAD_BALANCING keeps the route of lowest load among those that serve the request, the first of them on ties (a route
+        // only replaces the solution when its load is strictly lower, :571-575, :612-616); LOWEST_FRAGMENTATION the same with the
+        // route's score (:404-406).  Whether a route serves the request does not depend on the order the routes are examined
+        // in, so they are examined in ascending (load | score, index) order and the first one that serves is the answer.
+        if (POL == ONGYM_POLICY_LOAD_BALANCING) {
+            // load = np.sum(available_slots == 0) / len(path.links) (:568): compared as exact fractions (numerators <= 1023,
+            // denominators <= 64: two distinct fractions differ by far more than an fp64 rounding)
+            int v_busy = 0;
+            for (int k = 0; k < nk; k++) {
+                const PathRec pr = route_rec(k);
+                d_hops += pr.hops;
+                const int busy = S - (wave_sum_i32(__popc(path_and(mask_of(pr)))) - 1);     // the virtual slot S is the only bit beyond the row
+                if (lane == k) v_busy = busy;
+            }
+            v_rank = 0;
+            for (int j = 0; j < nk; j++) {
+                const int a = (int)rl((uint32_t)v_busy, j) * (int)v_hops, b = v_busy * (int)rl(v_hops, j);
+                v_rank += (a < b || (a == b && j < lane)) ? 1 : 0;
+            }
+            FSTAMP(13);
+        }
+        if (POL == ONGYM_POLICY_LOWEST_FRAGMENTATION) {
+            double v_score = 0.0;
+            for (int k = 0; k < nk; k++) {
+                const double sc = route_score((int)rl((uint32_t)v_path, k), (int)rl(v_hops, k));
+                d_hops += (int)rl(v_hops, k);
+                if (lane == k) v_score = sc;
+            }
+            v_rank = 0;
+            for (int j = 0; j < nk; j++) {
+                const double sj = readlane_f64(v_score, j);
+                v_rank += (sj < v_score || (sj == v_score && j < lane)) ? 1 : 0;
+            }
+            FSTAMP(13);
+        }
+
+        for (int r = 0; r < nk; r++) {
+            int k = r, path;
+            PathRec pr;
+            if (POL == ONGYM_POLICY_FIRST_FIT) {
+                path = k == 0 ? cur_p0 : uniform_i32(KC(P.pair_paths)[(cur_src * N + cur_dst) * K + k]);
+                if (path < 0) break;
+                // (fetching the first route's record already when the request is popped was measured 2.4 % SLOWER: eight more
+                //  live SGPRs across the departures scan cost more than the scalar-load latency they hide)
+                pr = load_path_rec(path_recs, path);
+                d_paths++; d_hops += pr.hops;
+            } else {
+                if (POL != ONGYM_POLICY_HIGHEST_SNR) k = __builtin_ctzll(__ballot(lane < nk && v_rank == r));
+                pr = route_rec(k);
+                path = (int)pr.id;
+                if (POL == ONGYM_POLICY_HIGHEST_SNR) d_hops += pr.hops;
+            }
             // modulations whose lower bound at slot 0 already fails cannot pass at any slot
             // lower bound of 1/GSNR at slot 0 = ASE(slot 0) + self-channel NLI (a few fp64 operations per lane: cheaper than
             // keeping their factors in registers for the whole launch)
-            const double t_bw = P.slot_bw * t_n, t_h = P.slot_bw * (t_n / 2.0);
-            const double lb = ((t_bw * (P.f0 + t_h)) * rp0) * pr.ase + (t_nlic * t_selfa) * pr.w1;
+            const double t_bw = P.slot_bw * w_n, t_h = P.slot_bw * (w_n / 2.0);
+            const double lb = ((t_bw * (P.f0 + t_h)) * rp0) * pr.ase + (w_nlic * w_selfa) * pr.w1;
             // (lb >= lim*(1+1e-9) => the full sum is at least that large up to rounding, and inside the 1e-9 band the
             //  dB-domain test rejects anything above lim: the skipped evaluation would have failed)
-            uint32_t feas = (uint32_t)(__ballot(lb < t_lim_hi) >> (8 * cur_bi)) & 0xFFu;
+            uint32_t feas = (uint32_t)(__ballot(lb < w_lim_hi) >> (8 * cur_bi)) & 0xFFu;
+            // HIGHEST_SNR: nor can a format beat the best candidate so far when its bound is not below that one's 1/GSNR
+            if (POL == ONGYM_POLICY_HIGHEST_SNR) feas &= (uint32_t)(__ballot(lb < best_acc) >> (8 * cur_bi));
             d_skips += M - __popc(feas);            // modulations settled by the bound (statistics only)
             FSTAMP(0);
             if (!feas) continue;
-            const uint64_t pmask = M64 ? ((uint64_t)pr.mask_lo | ((uint64_t)(pr.mask_hi & 0xFFFFFu) << 32)) : (uint64_t)pr.mask_lo;
+            const uint64_t pmask = mask_of(pr);
             uint32_t runs = path_and(pmask);
             FSTAMP(1);
-            int r = 1, L = -1;
-            uint32_t e_c2k[ENT], e_key4[ENT];
-            double e_w1[ENT], e_pw2[ENT];
-            int e_terms = 0;
+            int r_len = 1;
+            L = -1;
             while (feas) {
                 const int m = 31 - __builtin_clz(feas);            // best modulation first
                 feas &= ~(1u << m);
                 const int q = 8 * cur_bi + m;
                 const int n = (int)rl((uint32_t)t_n, q);
-                if (n + 1 < r) { runs = path_and(pmask); r = 1; }     // slot counts normally grow as the modulation index falls
-                runs = run_and32(runs, r, n + 1);
+                const int nn = POL == ONGYM_POLICY_LOWEST_FRAGMENTATION ? n + 1 : n;      // quirk: the request is sized slots + 1 (:357)
+                if (nn + 1 < r_len) { runs = path_and(pmask); r_len = 1; }     // slot counts normally grow as the modulation index falls
+                runs = run_and32(runs, r_len, nn + 1);
                 const int first = first_set32(runs);
                 FSTAMP(2);
                 if (first < 0) continue;
-                if (L < 0) {
-                    // ---- pass 1: interferers of this path -> LDS list -> registers (first 64*ENT of them)
-                    L = 0;
-                    for (int base = 0; base < active; base += 2 * kWave) {
-                        const int i0 = base + lane, i1 = i0 + kWave;
-                        const int i1c = min(i1, C);          // beyond the table: the neutral entry
-                        bool ov0 = (rec[i0].x & pr.mask_lo) != 0, ov1 = (rec[i1c].x & pr.mask_lo) != 0;    // unused entries: mask 0
-                        if (M64) { ov0 |= (a2[i0] & pr.mask_hi & 0xFFFFFu) != 0; ov1 |= (a2[i1c] & pr.mask_hi & 0xFFFFFu) != 0; }
-                        const uint64_t bal0 = __ballot(ov0), bal1 = __ballot(ov1);
-                        const int n0 = __popcll((unsigned long long)bal0);
-                        const int p0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal0, 0));
-                        const int p1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal1, 0));
-                        if (ov0) list[L + p0] = (uint16_t)i0;
-                        if (ov1) list[L + n0 + p1] = (uint16_t)i1;
-                        L += n0 + __popcll((unsigned long long)bal1);
-                    }
-                    wave_sync();
-                    FSTAMP(3);
-#pragma unroll
-                    for (int e = 0; e < ENT; e++) {
-#ifndef ONGYM_X_PREP_FLAT
-                        const int j = lane + kWave * e;
-                        e_c2k[e] = 0; e_key4[e] = 0; e_w1[e] = 0.0; e_pw2[e] = 0.0;
-                        if (j < L) {
-                            const int idx = list[j];
-                            const uint2 ab = rec[idx];
-                            e_c2k[e] = ab.y & 0x7FFu;
-                            e_key4[e] = ((ab.y >> 14) & 0x1FFu) << 15;
-                            uint32_t mm = ab.x & pr.mask_lo;
-                            double w1 = 0.0, w2 = 0.0;
-                            e_terms += __popc(mm);
-                            while (mm) { const int l = __ffs(mm) - 1; mm &= mm - 1; w1 += lw[2 * l]; w2 += lw[2 * l + 1]; }
-                            if (M64) {
-                                uint32_t mh = a2[idx] & pr.mask_hi & 0xFFFFFu;
-                                e_terms += __popc(mh);
-                                while (mh) { const int l = 32 + __ffs(mh) - 1; mh &= mh - 1; w1 += lw[2 * l]; w2 += lw[2 * l + 1]; }
-                            }
-                            e_w1[e] = w1;
-                            e_pw2[e] = phi[(ab.y >> 11) & 7u] * w2;
-                        }
-                    }
-                }
-#else
-                        // entry j of the list (a neutral record beyond L: rec[C] is padding with mask 0)
-                        const int j = lane + kWave * e;
-                        const int idx = j < L ? (int)list[j] : C;
-                        const uint2 ab = rec[idx];
-                        e_c2k[e] = ab.y & 0x7FFu;
-                        e_key4[e] = ((ab.y >> 14) & 0x1FFu) << 15;           // (n-1) * kTabPitch entries * 16 bytes
-                        uint32_t mm = ab.x & pr.mask_lo;
-                        e_terms += __popc(mm);
-                        // the weights of the first two shared links without a branch (most interferers share one or two);
-                        // link index E is the zero entry
-                        const int l0 = mm ? __ffs(mm) - 1 : E;
-                        mm &= mm - 1;
-                        const int l1 = mm ? __ffs(mm) - 1 : E;
-                        mm &= mm - 1;
-                        double w1 = lw[2 * l0] + lw[2 * l1], w2 = lw[2 * l0 + 1] + lw[2 * l1 + 1];
-                        if (__ballot(mm != 0)) while (mm) { const int l = __ffs(mm) - 1; mm &= mm - 1; w1 += lw[2 * l]; w2 += lw[2 * l + 1]; }
-                        if (M64) {
-                            uint32_t mh = a2[idx] & pr.mask_hi & 0xFFFFFu;
-                            e_terms += __popc(mh);
-                            if (__ballot(mh != 0)) while (mh) { const int l = 32 + __ffs(mh) - 1; mh &= mh - 1; w1 += lw[2 * l]; w2 += lw[2 * l + 1]; }
-                        }
-                        e_w1[e] = w1;
-                        e_pw2[e] = phi[(ab.y >> 11) & 7u] * w2;
-                    }
-                }
-#endif
-                // ---- pass 2: 1/GSNR of (path, first, n) ----
+                if (POL == ONGYM_POLICY_HIGHEST_SNR && !((__ballot(lb < best_acc) >> q) & 1ull)) continue;   // best_acc may have improved
+                if (L < 0) { build_cache(pr.mask_lo, pr.mask_hi); cache_path = path; }
                 FSTAMP(4);
-                const uint32_t c2 = (uint32_t)(2 * first + n);
-                double part = 0.0;
-                {
-                    TabPair t[ENT];
-#pragma unroll
-                    for (int e = 0; e < ENT; e++) {
-                        const uint32_t adi = __builtin_amdgcn_sad_u16(e_c2k[e], c2, 0);       // |c2k - c2|, both < 2^11
-                        t[e] = load_pair(tab, e_key4[e] | (adi << 4));
-                    }
-#pragma unroll
-                    for (int e = 0; e < ENT; e++) part += t[e].x * e_w1[e] - t[e].y * e_pw2[e];
+                if (POL == ONGYM_POLICY_HIGHEST_SNR) {
+                    const int cnt = compact_starts(runs);
+                    FSTAMP(14);
+                    eval_cands(cnt, nn, m, q, pr, k, path, pmask, w_nlic, w_selfa, w_lim_lo, w_lim_hi);
+                    FSTAMP(15);
+                    continue;
                 }
-                lane_terms += e_terms;
-                for (int base = kWave * ENT; base < L; base += kWave) {       // interferers beyond the register cache
-                    const int j = base + lane;
-                    if (j < L) {
-                        const int idx = list[j];
-                        const uint2 ab = rec[idx];
-                        const uint32_t adi = __builtin_amdgcn_sad_u16(ab.y & 0x7FFu, c2, 0);
-                        const TabPair t = load_pair(tab, (((ab.y >> 14) & 0x1FFu) << 15) | (adi << 4));
-                        uint32_t mm = ab.x & pr.mask_lo;
-                        double w1 = 0.0, w2 = 0.0;
-                        lane_terms += __popc(mm);
-                        while (mm) { const int l = __ffs(mm) - 1; mm &= mm - 1; w1 += lw[2 * l]; w2 += lw[2 * l + 1]; }
-                        if (M64) {
-                            uint32_t mh = a2[idx] & pr.mask_hi & 0xFFFFFu;
-                            lane_terms += __popc(mh);
-                            while (mh) { const int l = 32 + __ffs(mh) - 1; mh &= mh - 1; w1 += lw[2 * l]; w2 += lw[2 * l + 1]; }
-                        }
-                        part += t.x * w1 - t.y * (phi[(ab.y >> 11) & 7u] * w2);
-                    }
-                }
-                d_evals++;
-                const double tot = wave_sum(part);
-                // every lane finishes the evaluation for ITS (bit rate, modulation); lane q is the one that counts
-                const double fc = P.f0 + (P.slot_bw * first) + t_h;                  // envs/qrmsa.pyx:901-905
-                const double g_nli = t_nlic * (tot + pr.w1 * t_selfa);
-                const double g_ase = (t_bw * fc * pr.ase) * rp0;
-                const double acc = g_ase + g_nli;
-                int ok;
-                {
-                    const uint64_t yes = __ballot(acc <= t_lim_lo), no = __ballot(acc >= t_lim_hi);
-                    if ((yes >> q) & 1ull) ok = 1;
-                    else if ((no >> q) & 1ull) ok = 0;
-                    else {      // inside the 1e-9 band: the reference's own dB-domain expression (see qot_ok)
-                        const uint64_t db = __ballot(10.0 * log10(1.0 / acc) >= P.mod_thr[lane & 7] + *KC(&ge->margin));
-                        ok = (int)((db >> q) & 1ull);
-                    }
-                }
+                const int ok = eval_one(first, nn, q, pr, t_bw, t_h, w_nlic, w_selfa, w_lim_lo, w_lim_hi);
                 FSTAMP(5);
                 if (ok) {
                     ch_k = k; ch_m = m; ch_slot = first; ch_n = n; ch_path = path;
                     ch_mask = pmask;
-                    ch_acc = readlane_f64(acc, q);
-                    if (REC) { ch_ase = readlane_f64(g_ase, q); ch_nli = readlane_f64(g_nli, q); }
+                    ch_acc = ev_acc; ch_ase = ev_ase; ch_nli = ev_nli;
                     break;
                 }
+                if (POL == ONGYM_POLICY_LOWEST_FRAGMENTATION) {
+                    // the other starts of this format, 128 at a time, until one passes
+                    const uint32_t rest = lane == (first >> 5) ? runs & ~(1u << (first & 31)) : runs;
+                    const int cnt = compact_starts(rest);
+                    FSTAMP(14);
+                    const bool hit = cnt > 0 && eval_cands(cnt, nn, m, q, pr, k, path, pmask, w_nlic, w_selfa, w_lim_lo, w_lim_hi);
+                    FSTAMP(15);
+                    if (hit) break;
+                }
             }
-            if (ch_k >= 0) break;
+            if (POL != ONGYM_POLICY_HIGHEST_SNR && ch_k >= 0) break;
+        }
+        if (POL == ONGYM_POLICY_LOWEST_FRAGMENTATION && ch_k >= 0) {
+            // `env.step(action)` evaluates the GN model itself at the width the format needs (the heuristic asked for one slot
+            // more): the reference raises ValueError if that fails (envs/qrmsa.pyx:925-929) — a fused episode rejects the request
+            // and flags it (as k_run does)
+            const PathRec pr = load_path_rec(path_recs, ch_path);
+            if (cache_path != ch_path) { build_cache(pr.mask_lo, pr.mask_hi); cache_path = ch_path; }
+            const double s_bw = P.slot_bw * t_n, s_h = P.slot_bw * (t_n / 2.0);
+            if (eval_one(ch_slot, ch_n, 8 * cur_bi + ch_m, pr, s_bw, s_h, t_nlic, t_selfa, t_lim_lo, t_lim_hi)) {
+                ch_acc = ev_acc; ch_ase = ev_ase; ch_nli = ev_nli;
+            } else { ch_k = -1; lf_qot = true; }
         }
 
         // ================= step (envs/qrmsa.pyx:838-1065) ==============================================================
@@ -637,7 +930,31 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             if (osnr_prod < 1e-250) { if (lane == 0) cold[4] += -10.0 * log10(osnr_prod); osnr_prod = 1.0; wave_sync(); }
         } else {
             erej++;
-            if (ch_k < 0) {
+            if (ch_k < 0 && POL == ONGYM_POLICY_LOWEST_FRAGMENTATION && lf_qot) {
+                rflags |= ONGYM_F_QOT_ERROR | ONGYM_F_BLOCKED_OSNR;
+            } else if (ch_k < 0 && POL != ONGYM_POLICY_FIRST_FIT) {
+                // blocking flags of the heuristic's return tuple, exactly: nothing passed, so every (route, format) pair with a
+                // candidate start set any_blocked_osnr (its candidates failed) and every pair without one any_blocked_resources,
+                // which the return statement clears when any_blocked_osnr is set (heuristics.py:322-328, 410-414, 620-627).
+                // Candidates shrink as the slot count grows: a pair with candidates exists iff some route has a start for the
+                // smallest slot count.
+                int n_small = 0x7fffffff;
+                for (int m = M - 1; m >= 0; m--) {
+                    const int n = (int)rl((uint32_t)t_n, 8 * cur_bi + m);
+                    if (n > 0) n_small = min(n_small, n);
+                }
+                if (POL == ONGYM_POLICY_LOWEST_FRAGMENTATION) n_small += 1;
+                int bosnr = 0;
+                for (int k = 0; k < K && !bosnr && n_small <= S; k++) {
+                    const int path = uniform_i32(KC(P.pair_paths)[(cur_src * N + cur_dst) * K + k]);
+                    if (path < 0) break;
+                    const PathRec pr = load_path_rec(path_recs, path);
+                    const uint32_t x = path_and(M64 ? ((uint64_t)pr.mask_lo | ((uint64_t)(pr.mask_hi & 0xFFFFFu) << 32)) : (uint64_t)pr.mask_lo);
+                    int r1 = 1;
+                    if (first_set32(run_and32(x, r1, n_small + 1)) >= 0) bosnr = 1;
+                }
+                rflags |= bosnr ? ONGYM_F_BLOCKED_OSNR : ONGYM_F_BLOCKED_RESOURCES;
+            } else if (ch_k < 0) {
                 // blocking flags of the heuristic's return tuple, exactly: a (path, modulation) pair without candidates sets
                 // blocked_resources, one with candidates clears it and sets blocked_osnr (none passed, or we would not be
                 // here).  Candidates shrink as the slot count grows, so only the smallest and, on the last path, the

@@ -10,8 +10,13 @@
 #include <string>
 #include <vector>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "ongym_device.hpp"
-#include "ongym_fast.hpp"
+#include "ongym_host.hpp"
+#include "ongym_fast.hpp"      // fast_lds_bytes, PathRec (the kernels themselves: ongym_fast.hip)
 #include "ongym_scored.hpp"
 
 using namespace ongym;
@@ -108,14 +113,6 @@ __global__ __launch_bounds__(64, WAVES) void k_run(const Params *__restrict__ Pp
     if (c.lane == 0 && P.dbg)
         for (int i = 0; i < ONGYM_NSTAMPS; i++) atomicAdd(&P.dbg[i], c.stamp_acc[i]);
 #endif
-}
-
-// The lean fused first-fit kernel (ongym_fast.hpp).  M64: link masks need two words (32 < n_links <= 52);
-// ENT: interferers per lane cached in registers; WAVES: waves per SIMD the register allocation is bounded for.
-template <bool M64, bool REC, int ENT, int WAVES, bool TRACE = false>
-__global__ __launch_bounds__(64, WAVES) void k_fast(const Params *__restrict__ Pp, int nsteps, ongym_step_rec *out) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    fast_run<M64, REC, ENT, TRACE>(*Pp, nsteps, out, smem);
 }
 
 __global__ __launch_bounds__(64) void k_reset(const Params *__restrict__ Pp, const uint8_t *mask) {
@@ -308,52 +305,17 @@ __global__ __launch_bounds__(64) void k_query(const Params *__restrict__ Pp, int
     }
 }
 
+static std::string g_create_error;
+
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-struct ongym_env {
-    ongym_config cfg{};
-    Params P{};
-    Params *d_P = nullptr;          // device copy read by the kernels (scalar loads); refreshed by push_params
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
-    size_t lds = 0;
-    std::vector<void *> allocs;
-    std::string err;
-    void *d_trace = nullptr;        // owned copy of a host trace
-    ongym_step_rec *d_out = nullptr; size_t d_out_n = 0;
-    int32_t *d_actions = nullptr; int32_t *d_act_out = nullptr; uint8_t *d_flag_out = nullptr; uint8_t *d_mask = nullptr;
-    float *d_obs = nullptr; uint8_t *d_obsmask = nullptr;   // lazily allocated staging for ongym_observe with host buffers
-    int32_t *d_scratch_i = nullptr; size_t scratch_i_bytes = 0; double *d_scratch_d = nullptr;
-    bool has_source = false;
-    std::vector<double> cfg_bit_rates;     // host copy of the discrete bit rates
-    bool fast_ok = false;           // the configuration is eligible for k_fast (see fast_eligible)
-    bool fast_m64 = false;
-    int fast_waves = 4;             // waves per SIMD of the k_fast instantiation that runs (register budget 512 / waves)
-    bool trace_used = false;        // a trace the lean kernel cannot replay was installed: its records may not fit the lean codec
-    bool trace_fast_ok = false;     // the installed (host) trace only carries bit rates of the configured table
-    size_t fast_lds = 0;
-};
-
-#define HIP_TRY(env, expr)                                                                               \
-    do {                                                                                                 \
-        hipError_t _e = (expr);                                                                          \
-        if (_e != hipSuccess) {                                                                          \
-            (env)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                              \
-            return ONGYM_E_HIP;                                                                          \
-        }                                                                                                \
-    } while (0)
-
-static std::string g_create_error;
-
-// hipFuncAttributeMaxDynamicSharedMemorySize is a per-kernel, process-wide setting: keep the largest request ever made
-// (an environment with a smaller LDS block must not lower the limit under one created earlier) and only ever raise it.
-#include <map>
-static hipError_t raise_lds_limit(const void *kernel, size_t bytes) {
-    static std::map<const void *, size_t> limit;
+static std::mutex g_lds_mutex;
+hipError_t raise_lds_limit(int device, const void *kernel, size_t bytes) {
+    static std::map<std::pair<int, const void *>, size_t> limit;
     if (bytes <= 64 * 1024) return hipSuccess;        // the default limit covers it
-    size_t &cur = limit[kernel];
+    std::lock_guard<std::mutex> lock(g_lds_mutex);
+    size_t &cur = limit[std::make_pair(device, kernel)];
     if (bytes <= cur) return hipSuccess;
     const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e == hipSuccess) cur = bytes;
@@ -635,10 +597,6 @@ static int build(ongym_env *env, const ongym_config *c) {
             if ((rc = upload(env, recs.data(), recs.size(), &d_recs))) return rc;
             P.path_rec = d_recs;
             env->fast_ok = true; env->fast_m64 = m64; env->fast_lds = flds;
-            // gfx950 hands out LDS in 1280-byte granules (160 KiB / 128; measured: 8160 B per workgroup gave 18 workgroups per
-            // CU, 7648 B gave 20): pick the instantiation whose register budget matches the replicas the LDS admits
-            const size_t granule = 1280, per_cu = (160 * 1024) / (((flds + granule - 1) / granule) * granule);
-            env->fast_waves = m64 ? 3 : (per_cu >= 17 ? 5 : 4);
         }
     }
 
@@ -683,7 +641,7 @@ static int build(ongym_env *env, const ongym_config *c) {
     env->lds = lds_bytes(P);
     if (env->lds > 64 * 1024) {
         if (env->lds > 160 * 1024) return fail_arg(env, "state does not fit the 160 KiB LDS: lower capacity", ONGYM_E_LIMIT);
-#define ONGYM_SET_LDS(K) HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&K), env->lds))
+#define ONGYM_SET_LDS(K) HIP_TRY(env, raise_lds_limit(env->cfg.device, reinterpret_cast<const void *>(&K), env->lds))
         ONGYM_SET_LDS((k_run<true, true, 4, 0>)); ONGYM_SET_LDS((k_run<true, false, 4, 0>));
         ONGYM_SET_LDS((k_run<false, true, 4, 0>)); ONGYM_SET_LDS((k_run<false, false, 4, 0>));
         ONGYM_SET_LDS((k_run<true, true, 4, 1>)); ONGYM_SET_LDS((k_run<true, false, 4, 1>));
@@ -702,15 +660,13 @@ static int build(ongym_env *env, const ongym_config *c) {
         ONGYM_SET_LDS(k_reset);
 #undef ONGYM_SET_LDS
     }
-    if (env->fast_ok && env->fast_lds > 64 * 1024) {
-#define ONGYM_SET_FLDS(K) HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&K), env->fast_lds))
-        ONGYM_SET_FLDS((k_fast<false, false, 2, 4>)); ONGYM_SET_FLDS((k_fast<false, true, 2, 4>));
-        ONGYM_SET_FLDS((k_fast<false, false, 2, 5>)); ONGYM_SET_FLDS((k_fast<false, true, 2, 5>));
-        ONGYM_SET_FLDS((k_fast<true, false, 4, 3>)); ONGYM_SET_FLDS((k_fast<true, true, 4, 3>));
-        ONGYM_SET_FLDS((k_fast<false, false, 2, 4, true>)); ONGYM_SET_FLDS((k_fast<false, true, 2, 4, true>));
-        ONGYM_SET_FLDS((k_fast<false, false, 2, 5, true>)); ONGYM_SET_FLDS((k_fast<false, true, 2, 5, true>));
-        ONGYM_SET_FLDS((k_fast<true, false, 4, 3, true>)); ONGYM_SET_FLDS((k_fast<true, true, 4, 3, true>));
-#undef ONGYM_SET_FLDS
+    if (env->fast_ok) {   // the lean kernels of every policy that has one (ongym_fast.hip): LDS limits; a policy whose block
+                          // does not fit the CU keeps the generic kernel
+        if (fast_prepare_p0(env)) env->fast_ok = false;
+        env->fast_lb_ok = env->fast_ok && fast_prepare_p1(env) == 0;
+        env->fast_hsnr_ok = env->fast_ok && fast_prepare_p2(env) == 0;
+        env->fast_lf_ok = env->fast_ok && fast_prepare_p10(env) == 0;
+        env->err.clear();
     }
     // scratch for queries / host-buffer I/O
     env->scratch_i_bytes = std::max(std::max((size_t)E * c->n_slots * 4, (size_t)c->capacity * sizeof(ongym_service) + 16), (size_t)2048 * 4);
@@ -793,18 +749,40 @@ void ongym_destroy(ongym_env *env) {
 
 /* Resident workgroups (= replicas = wavefronts) per compute unit of the kernel that ongym_step_policy(first fit) launches,
  * as the HIP occupancy query reports it for this environment's LDS size. Diagnostic. */
+static bool lean_policy(const ongym_env *env, int policy) {      // does ongym_step_policy(policy) run a lean kernel?
+    if (!env->fast_ok || env->trace_used) return false;
+    if (!(env->P.req_mode == kReqRng || (env->P.req_mode == kReqTrace && env->trace_fast_ok))) return false;
+    switch (policy) {
+        case ONGYM_POLICY_FIRST_FIT: return true;
+        case ONGYM_POLICY_LOAD_BALANCING: return env->fast_lb_ok;
+        case ONGYM_POLICY_HIGHEST_SNR: return env->fast_hsnr_ok;
+        case ONGYM_POLICY_LOWEST_FRAGMENTATION: return env->fast_lf_ok;
+        default: return false;
+    }
+}
+
 int ongym_query_occupancy(ongym_env *env, int32_t *blocks_per_cu, int32_t *lds_bytes, int32_t *lean_kernel) {
+    return ongym_query_occupancy_policy(env, ONGYM_POLICY_FIRST_FIT, blocks_per_cu, lds_bytes, lean_kernel);
+}
+
+int ongym_query_occupancy_policy(ongym_env *env, int32_t policy, int32_t *blocks_per_cu, int32_t *lds_bytes, int32_t *lean_kernel) {
     if (!env || !blocks_per_cu || !lds_bytes || !lean_kernel) return ONGYM_E_ARG;
+    if (policy < ONGYM_POLICY_FIRST_FIT || policy >= ONGYM_POLICY_COUNT) return fail_arg(env, "unknown policy id");
     HIP_TRY(env, hipSetDevice(env->cfg.device));
-    int nb = 0;
-    const bool lean = env->fast_ok && !env->trace_used &&
-                      (env->P.req_mode == kReqRng || (env->P.req_mode == kReqTrace && env->trace_fast_ok));
+    int nb = 0, lds = 0;
+    const bool lean = lean_policy(env, policy);
     if (lean) {
-        if (env->fast_m64) HIP_TRY(env, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<true, false, 4, 3>, 64, env->fast_lds));
-        else if (env->fast_waves == 5) HIP_TRY(env, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<false, false, 2, 5>, 64, env->fast_lds));
-        else HIP_TRY(env, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<false, false, 2, 4>, 64, env->fast_lds));
-        *lds_bytes = (int32_t)env->fast_lds;
+        int rc;
+        switch (policy) {
+            case ONGYM_POLICY_LOAD_BALANCING: rc = fast_occupancy_p1(env, &nb, &lds); break;
+            case ONGYM_POLICY_HIGHEST_SNR: rc = fast_occupancy_p2(env, &nb, &lds); break;
+            case ONGYM_POLICY_LOWEST_FRAGMENTATION: rc = fast_occupancy_p10(env, &nb, &lds); break;
+            default: rc = fast_occupancy_p0(env, &nb, &lds); break;
+        }
+        if (rc) return rc;
+        *lds_bytes = lds;
     } else {
+        // the generic kernel's state block (the policies with scratch ask for more at launch time)
         if (env->lds <= 8192) HIP_TRY(env, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_run<true, true, 5, 0>, 64, env->lds));
         else HIP_TRY(env, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_run<true, true, 4, 0>, 64, env->lds));
         *lds_bytes = (int32_t)env->lds;
@@ -941,31 +919,25 @@ static int launch_run(ongym_env *env, int mode, int policy, int nsteps, const in
                       uint8_t *d_flag_out, ongym_step_rec *d_out) {
     HIP_TRY(env, hipEventRecord(env->ev0, env->stream));
     const dim3 grid(env->P.batch), block(64);
-    if (mode == kModePolicyStep && policy == ONGYM_POLICY_FIRST_FIT && env->fast_ok && !env->trace_used &&
-        (env->P.req_mode == kReqRng || (env->P.req_mode == kReqTrace && env->trace_fast_ok))) {
-        // the lean kernel: same results, half the issued instructions (ongym_fast.hpp)
-        const bool tr = env->P.req_mode == kReqTrace;
-#define ONGYM_LAUNCH_FAST(M64, ENT, WAVES)                                                                         \
-    do {                                                                                                           \
-        if (tr && d_out) hipLaunchKernelGGL((k_fast<M64, true, ENT, WAVES, true>), grid, block, env->fast_lds, env->stream, env->d_P, nsteps, d_out); \
-        else if (tr) hipLaunchKernelGGL((k_fast<M64, false, ENT, WAVES, true>), grid, block, env->fast_lds, env->stream, env->d_P, nsteps, d_out);  \
-        else if (d_out) hipLaunchKernelGGL((k_fast<M64, true, ENT, WAVES>), grid, block, env->fast_lds, env->stream, env->d_P, nsteps, d_out); \
-        else hipLaunchKernelGGL((k_fast<M64, false, ENT, WAVES>), grid, block, env->fast_lds, env->stream, env->d_P, nsteps, d_out);      \
-    } while (0)
-        if (env->fast_m64) ONGYM_LAUNCH_FAST(true, 4, 3);
-        else if (env->fast_waves == 5) ONGYM_LAUNCH_FAST(false, 2, 5);
-        else ONGYM_LAUNCH_FAST(false, 2, 4);
-#undef ONGYM_LAUNCH_FAST
-        HIP_TRY(env, hipGetLastError());
+    if (mode == kModePolicyStep && lean_policy(env, policy)) {
+        // the lean kernels: same results, half the issued instructions (ongym_fast.hpp)
+        int rc;
+        switch (policy) {
+            case ONGYM_POLICY_LOAD_BALANCING: rc = fast_launch_p1(env, nsteps, d_out); break;
+            case ONGYM_POLICY_HIGHEST_SNR: rc = fast_launch_p2(env, nsteps, d_out); break;
+            case ONGYM_POLICY_LOWEST_FRAGMENTATION: rc = fast_launch_p10(env, nsteps, d_out); break;
+            default: rc = fast_launch_p0(env, nsteps, d_out); break;
+        }
+        if (rc) return rc;
         HIP_TRY(env, hipEventRecord(env->ev1, env->stream));
         env->timed = true;
         return 0;
     }
     if (policy == ONGYM_POLICY_HIGHEST_SNR && field_lds(env) > 64 * 1024) {
-        HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<true, true, 4, ONGYM_POLICY_HIGHEST_SNR>), field_lds(env)));
-        HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<true, false, 4, ONGYM_POLICY_HIGHEST_SNR>), field_lds(env)));
-        HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<false, true, 4, ONGYM_POLICY_HIGHEST_SNR>), field_lds(env)));
-        HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<false, false, 4, ONGYM_POLICY_HIGHEST_SNR>), field_lds(env)));
+        HIP_TRY(env, raise_lds_limit(env->cfg.device, reinterpret_cast<const void *>(&k_run<true, true, 4, ONGYM_POLICY_HIGHEST_SNR>), field_lds(env)));
+        HIP_TRY(env, raise_lds_limit(env->cfg.device, reinterpret_cast<const void *>(&k_run<true, false, 4, ONGYM_POLICY_HIGHEST_SNR>), field_lds(env)));
+        HIP_TRY(env, raise_lds_limit(env->cfg.device, reinterpret_cast<const void *>(&k_run<false, true, 4, ONGYM_POLICY_HIGHEST_SNR>), field_lds(env)));
+        HIP_TRY(env, raise_lds_limit(env->cfg.device, reinterpret_cast<const void *>(&k_run<false, false, 4, ONGYM_POLICY_HIGHEST_SNR>), field_lds(env)));
     }
 #define ONGYM_LAUNCH_DEFRAG(R, POL, LDS)                                                                           \
     hipLaunchKernelGGL((k_run<true, R, 4, POL, true>), grid, block, LDS, env->stream, env->d_P, mode, nsteps,      \
@@ -973,8 +945,8 @@ static int launch_run(ongym_env *env, int mode, int policy, int nsteps, const in
     if (env->P.track_ids) {   // defragmentation / service-id tracking (uniform attenuation, checked at create): own instantiations
         if (policy == ONGYM_POLICY_HIGHEST_SNR) {
             if (field_lds(env) > 64 * 1024) {
-                HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<true, true, 4, ONGYM_POLICY_HIGHEST_SNR, true>), field_lds(env)));
-                HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<true, false, 4, ONGYM_POLICY_HIGHEST_SNR, true>), field_lds(env)));
+                HIP_TRY(env, raise_lds_limit(env->cfg.device, reinterpret_cast<const void *>(&k_run<true, true, 4, ONGYM_POLICY_HIGHEST_SNR, true>), field_lds(env)));
+                HIP_TRY(env, raise_lds_limit(env->cfg.device, reinterpret_cast<const void *>(&k_run<true, false, 4, ONGYM_POLICY_HIGHEST_SNR, true>), field_lds(env)));
             }
             if (env->P.rec32) ONGYM_LAUNCH_DEFRAG(true, ONGYM_POLICY_HIGHEST_SNR, field_lds(env));
             else ONGYM_LAUNCH_DEFRAG(false, ONGYM_POLICY_HIGHEST_SNR, field_lds(env));
@@ -983,8 +955,8 @@ static int launch_run(ongym_env *env, int mode, int policy, int nsteps, const in
             else ONGYM_LAUNCH_DEFRAG(false, ONGYM_POLICY_LOAD_BALANCING, env->lds);
         } else if (policy >= ONGYM_POLICY_LOWEST_FRAGMENTATION) {
             if (scored_lds(env, policy) > 64 * 1024) {
-                HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<true, true, 4, kPolicyScored, true>), scored_lds(env, policy)));
-                HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<true, false, 4, kPolicyScored, true>), scored_lds(env, policy)));
+                HIP_TRY(env, raise_lds_limit(env->cfg.device, reinterpret_cast<const void *>(&k_run<true, true, 4, kPolicyScored, true>), scored_lds(env, policy)));
+                HIP_TRY(env, raise_lds_limit(env->cfg.device, reinterpret_cast<const void *>(&k_run<true, false, 4, kPolicyScored, true>), scored_lds(env, policy)));
             }
             if (env->P.rec32) ONGYM_LAUNCH_DEFRAG(true, kPolicyScored, scored_lds(env, policy));
             else ONGYM_LAUNCH_DEFRAG(false, kPolicyScored, scored_lds(env, policy));
@@ -1011,7 +983,7 @@ static int launch_run(ongym_env *env, int mode, int policy, int nsteps, const in
                                env->d_P, mode, nsteps, d_actions, d_act_out, d_flag_out, d_out, policy);                   \
         else if (policy >= ONGYM_POLICY_LOWEST_FRAGMENTATION) {                                                    \
             if (scored_lds(env, policy) > 64 * 1024)                                                                       \
-                HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_run<UA, R, 4, kPolicyScored>), scored_lds(env, policy))); \
+                HIP_TRY(env, raise_lds_limit(env->cfg.device, reinterpret_cast<const void *>(&k_run<UA, R, 4, kPolicyScored>), scored_lds(env, policy))); \
             hipLaunchKernelGGL((k_run<UA, R, 4, kPolicyScored>), grid, block, scored_lds(env, policy), env->stream,         \
                                env->d_P, mode, nsteps, d_actions, d_act_out, d_flag_out, d_out, policy);                   \
         } else if (policy >= ONGYM_POLICY_LOWEST_SPECTRUM)                                                         \
@@ -1092,10 +1064,10 @@ int ongym_observe(ongym_env *env, float *obs, uint8_t *mask) {
     const size_t B = (size_t)P.batch;
     const size_t lds = observe_lds(env);
     if (lds > 64 * 1024) {
-        HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_observe<true, true>), lds));
-        HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_observe<true, false>), lds));
-        HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_observe<false, true>), lds));
-        HIP_TRY(env, raise_lds_limit(reinterpret_cast<const void *>(&k_observe<false, false>), lds));
+        HIP_TRY(env, raise_lds_limit(env->cfg.device, reinterpret_cast<const void *>(&k_observe<true, true>), lds));
+        HIP_TRY(env, raise_lds_limit(env->cfg.device, reinterpret_cast<const void *>(&k_observe<true, false>), lds));
+        HIP_TRY(env, raise_lds_limit(env->cfg.device, reinterpret_cast<const void *>(&k_observe<false, true>), lds));
+        HIP_TRY(env, raise_lds_limit(env->cfg.device, reinterpret_cast<const void *>(&k_observe<false, false>), lds));
     }
     float *d_obs = obs; uint8_t *d_mask = mask;
     if (!env->cfg.io_device) {

@@ -211,6 +211,7 @@ def _declare(lib):
     lib.ongym_query_request.argtypes = [vp, C.c_int32, vp]
     lib.ongym_stats_get.argtypes = [vp, vp]
     lib.ongym_query_occupancy.argtypes = [vp, vp, vp, vp]
+    lib.ongym_query_occupancy_policy.argtypes = [vp, C.c_int32, vp, vp, vp]
     lib.ongym_sync.argtypes = [vp]
     lib.ongym_last_kernel_ms.argtypes = [vp]
     lib.ongym_last_kernel_ms.restype = C.c_double
@@ -221,7 +222,7 @@ def _declare(lib):
     for name in ("ongym_create", "ongym_seed", "ongym_seed_base", "ongym_set_requests", "ongym_reset", "ongym_reset_episode_counters", "ongym_step_policy",
                  "ongym_step_actions", "ongym_policy_actions", "ongym_observe", "ongym_query_available", "ongym_query_gsnr", "ongym_query_gsnr_many", "ongym_query_moves",
                  "ongym_query_grid", "ongym_query_services", "ongym_query_request", "ongym_stats_get", "ongym_sync",
-                 "ongym_abi_version", "ongym_sizeof", "ongym_query_candidates", "ongym_query_path_free", "ongym_observe", "ongym_query_occupancy"):
+                 "ongym_abi_version", "ongym_sizeof", "ongym_query_candidates", "ongym_query_path_free", "ongym_observe", "ongym_query_occupancy", "ongym_query_occupancy_policy"):
         getattr(lib, name).restype = C.c_int32
 
 
@@ -229,7 +230,7 @@ EXPORTED_SYMBOLS = (
     "ongym_create", "ongym_destroy", "ongym_seed", "ongym_seed_base", "ongym_set_requests", "ongym_reset", "ongym_reset_episode_counters", "ongym_step_policy",
     "ongym_step_actions", "ongym_policy_actions", "ongym_observe", "ongym_query_available", "ongym_query_gsnr", "ongym_query_gsnr_many", "ongym_query_moves", "ongym_query_grid",
     "ongym_query_services", "ongym_query_request", "ongym_query_candidates", "ongym_query_path_free",
-    "ongym_stats_get", "ongym_sync", "ongym_last_kernel_ms", "ongym_query_occupancy",
+    "ongym_stats_get", "ongym_sync", "ongym_last_kernel_ms", "ongym_query_occupancy", "ongym_query_occupancy_policy",
     "ongym_last_error", "ongym_abi_version", "ongym_sizeof")
 
 

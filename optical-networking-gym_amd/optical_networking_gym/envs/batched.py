@@ -210,11 +210,12 @@ class BatchedQRMSAEnv:
         self._check(self.lib.ongym_stats_get(self._h, out.ctypes.data), "ongym_stats_get")
         return out
 
-    def occupancy(self) -> dict:
-        """Resident replicas (wavefronts) per compute unit of the first-fit step kernel, its LDS bytes per replica, and
-        whether the lean kernel is the one that runs."""
+    def occupancy(self, policy: int = nat.POLICY_FIRST_FIT) -> dict:
+        """Resident replicas (wavefronts) per compute unit of the kernel step_policy(policy=...) launches, its LDS bytes per
+        replica, and whether a lean kernel is the one that runs."""
         nb, lds, lean = C.c_int32(0), C.c_int32(0), C.c_int32(0)
-        self._check(self.lib.ongym_query_occupancy(self._h, C.byref(nb), C.byref(lds), C.byref(lean)), "ongym_query_occupancy")
+        self._check(self.lib.ongym_query_occupancy_policy(self._h, int(policy), C.byref(nb), C.byref(lds), C.byref(lean)),
+                    "ongym_query_occupancy_policy")
         return dict(blocks_per_cu=nb.value, lds_bytes=lds.value, lean_kernel=bool(lean.value))
 
     def sync(self):

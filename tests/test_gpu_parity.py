@@ -697,6 +697,47 @@ def test_bench_size_batch_65536_properties_and_sampled_oracle():
         np.testing.assert_array_equal(a.grid(r), o.grid())
 
 
+@pytest.mark.parametrize("topo,S,load,capacity,B,blocks_per_cu,nsample",
+                         [("cost239", 320, 400, 512, 16384, 18, 40),       # BASELINE config 3 as bench.py --workload cost239_320 times it
+                          ("nobel-eu", 768, 600, 704, 65536, None, 32)])   # BASELINE config 4 (bench.py --workload nobeleu768)
+def test_bench_shape_c3_c4_sampled_oracle(topo, S, load, capacity, B, blocks_per_cu, nsample):
+    """The kernels the C3 / C4 bench lines time, at the bench's own shape (capacity, batch, record=False, 250-step
+    launches): the record-free lean instantiation (for nobel-eu the M64 codec) is held to the oracle on sampled replicas —
+    counters, clocks, mean GSNR of the finished episode and the whole grid.  Semantics: envs/qrmsa.pyx:838-1122,
+    heuristics/heuristics.py:923-966."""
+    tb = golden_tables(topo)
+    steps = 1250
+    kw = dict(tables=tb, modulations=jocn_modulations(), batch_size=B, num_spectrum_resources=S, capacity=capacity,
+              load=load, bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), episode_length=1000)
+    a = BatchedQRMSAEnv(**kw); a.seed(1); a.reset()
+    occ = a.occupancy()
+    assert occ["lean_kernel"]
+    if blocks_per_cu is not None:
+        assert occ["blocks_per_cu"] == blocks_per_cu           # what profiles/*_bench.json report for this workload
+    else:
+        assert occ["blocks_per_cu"] >= 9                        # round 2: 9 (17 408 B of LDS per replica)
+    for _ in range(steps // 250):
+        a.step_policy(250, record=False)
+    sa = a.stats()
+    assert not (sa["flags"] & nat.F_OVERFLOW).any() and sa["active"].max() < capacity
+    assert (sa["total_steps"] == steps).all() and (sa["episodes_completed"] == 1).all()
+    assert (sa["episode_services_accepted"] + sa["rejected"] == sa["episode_services_processed"] - 1).all()
+    holder = nat.ConfigHolder(tb, modulations=jocn_modulations(), num_spectrum_resources=S, batch=B, capacity=capacity,
+                              load=load, bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), episode_length=1000,
+                              auto_reset=True)
+    rng = np.random.default_rng(11)
+    for r in [0, 1, B - 1] + [int(x) for x in rng.integers(2, B - 1, nsample - 3)]:
+        check_state_invariants(a, tb, r, S)
+        o = OracleEnv(holder, replica=r)
+        o.seed(1); o.reset(); o.run_first_fit(steps)
+        so = o.stats()
+        for f in ("services_accepted", "episode_services_accepted", "rejected", "bit_rate_provisioned", "active",
+                  "current_time", "last_episode_accepted", "last_service_blocking_rate", "total_paths_tried"):
+            assert sa[r][f] == so[f], (r, f)
+        assert sa[r]["last_mean_gsnr"] == pytest.approx(so["last_mean_gsnr"], rel=1e-9)
+        np.testing.assert_array_equal(a.grid(r), o.grid())
+
+
 @pytest.mark.parametrize("tag", ["traj_nsfnet320_lb", "traj_nobeleu320_lb", "traj_nsfnet128_hsnr"])
 def test_other_fused_policies_vs_reference(tag):
     """fused load_balancing_best_modulation (heuristics.py:547-627) / heuristic_highest_snr (:272-328) against the

@@ -9,13 +9,18 @@ for spec in "$@"; do
   name=${spec%%:*}; flags=""; [[ "$spec" == *:* ]] && flags=${spec#*:}
   if [ "$name" == "head" ]; then
     T=$(mktemp -d); mkdir -p $T/optical-networking-gym_amd/csrc $T/include
-    for f in ongym_hip.hip $(cd $CSRC && ls *.hpp); do git -C $REPO show HEAD:optical-networking-gym_amd/csrc/$f > $T/optical-networking-gym_amd/csrc/$f; done
+    for f in $(git -C $REPO ls-tree --name-only HEAD optical-networking-gym_amd/csrc/ | xargs -n1 basename | grep -E '\.(hip|hpp)$'); do git -C $REPO show HEAD:optical-networking-gym_amd/csrc/$f > $T/optical-networking-gym_amd/csrc/$f; done
     for f in ongym.h ongym_traffic.h; do git -C $REPO show HEAD:include/$f > $T/include/$f; done
-    SRC=$T/optical-networking-gym_amd/csrc/ongym_hip.hip
+    # (round-2 sources are one translation unit; later ones carry their own build recipe)
+    if git -C $REPO cat-file -e HEAD:optical-networking-gym_amd/csrc/ongym_fast.hip 2>/dev/null; then
+      git -C $REPO show HEAD:__graft_entry__.py > $T/__graft_entry__.py
+      (cd $T && python3 __graft_entry__.py --variant head -w $flags && cp $T/optical-networking-gym_amd/csrc/variants/lib_head.so $CSRC/variants/) &
+    else
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -w $flags -o $CSRC/variants/lib_$name.so $T/optical-networking-gym_amd/csrc/ongym_hip.hip &
+    fi
   else
-    SRC=$CSRC/ongym_hip.hip
+    (cd $REPO && python3 __graft_entry__.py --variant $name -w $flags) &
   fi
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -w $flags -o $CSRC/variants/lib_$name.so $SRC &
 done
 wait
 ls -la $CSRC/variants/

@@ -18,7 +18,7 @@ for pid in ids:
                           load=wl["load"], bit_rate_selection="discrete", bit_rates=wl["bit_rates"])
     env.seed(1); env.reset()
     env.step_policy(800, record=False); env.sync()            # near steady state with first fit (episodes are 1000 steps:
-    n = steps if pid < 10 else max(steps // 10, 5)           # the timed steps stay inside the first one)
+    n = steps if pid != 11 else max(steps // 10, 5)          # the timed steps stay inside the first one)
     assert 800 + n < 1000
     env.step_policy(n, record=False, policy=pid); env.sync()
     ms = env.last_kernel_ms()
