@@ -80,22 +80,45 @@ def algorithmic_bytes_per_step(stats_sum, S):
                    mean_active_services=A)
 
 
-def pmc_summary(workload):
-    """Counter summary of the dominant kernel for this workload, from the rocprofv3 --pmc passes committed under
+def kernel_source_hash():
+    """sha256 over the kernel sources (csrc/*.hip, csrc/*.hpp, include/*.h, sorted by name): tools/pmc_summarise.py stores
+    it with every counter summary, bench.py compares it with the sources it runs and marks a summary of other sources stale."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(REPO, "optical-networking-gym_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")) +
+                    glob.glob(os.path.join(REPO, "include", "*.h"))):
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_key(workload, policy):
+    return workload if policy == 0 else f"{workload}_p{policy}"
+
+
+def pmc_summary(workload, policy=0):
+    """Counter summary of the dominant kernel for this workload and policy, from the rocprofv3 --pmc passes committed under
     profiles/ (collected in separate runs as MI355X_MICROARCH.md prescribes; bench.py cannot run the profiler on
-    itself).  None when no profile of the current kernel is tracked."""
+    itself).  None when no profile is tracked; `stale` is set when it was collected on other kernel sources."""
     path = os.path.join(REPO, "profiles", "pmc_summary.json")
     try:
         with open(path) as f:
-            return json.load(f).get(workload)
+            summ = json.load(f).get(pmc_key(workload, policy))
     except (OSError, ValueError):
         return None
+    if summ is not None:
+        summ = dict(summ)
+        summ["stale"] = summ.get("kernel_source_sha") != kernel_source_hash()
+    return summ
 
 
-def cpu_baseline(tables, wl, workload, seconds_target=12.0):
+def cpu_baseline(tables, wl, workload, policy=0, seconds_target=12.0):
     """The CPU oracle (C restatement of the reference, oracle/) on this box's host cores, bounded sample."""
     from optical_networking_gym import _native as nat
-    from oracle_lib import OracleEnv, batch_run_first_fit
+    from oracle_lib import OracleEnv, batch_run_first_fit, batch_run_policy
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = max(1, min(cores, 64))
     nrep = threads * 2
@@ -108,21 +131,46 @@ def cpu_baseline(tables, wl, workload, seconds_target=12.0):
         o.seed(1)
         o.reset()
         envs.append(o)
-    batch_run_first_fit(envs, 999, threads)          # warm-up episode (fills the network), untimed
-    done, t0 = 0, time.perf_counter()
-    while True:
-        done += batch_run_first_fit(envs, 999, threads)
+    if policy == 0:
+        batch_run_first_fit(envs, 999, threads)          # warm-up episode (fills the network), untimed
+        done, t0 = 0, time.perf_counter()
+        while True:
+            done += batch_run_first_fit(envs, 999, threads)
+            dt = time.perf_counter() - t0
+            if dt >= seconds_target or done >= 40 * 999 * nrep:
+                break
+        sample = (f"{nrep} replicas x {done // nrep} steps of the same workload after a 999-step warm-up, "
+                  f"OpenMP over replicas, {dt:.1f} s")
+    else:
+        # the heuristics that evaluate many candidates run at tens of steps per second per core in the port: the network is
+        # filled by 700 first-fit steps (untimed), then the policy runs in slices sized from the first one
+        batch_run_first_fit(envs, 700, threads)
+        t0 = time.perf_counter()
+        done = batch_run_policy(envs, policy, 10, threads)
         dt = time.perf_counter() - t0
-        if dt >= seconds_target or done >= 40 * 999 * nrep:
-            break
-    out = dict(value=done / dt, unit="env-steps/s", cores=threads, kind="port",
-               sample=f"{nrep} replicas x {done // nrep} steps of the same workload after a 999-step warm-up, "
-                      f"OpenMP over replicas, {dt:.1f} s")
-    if workload in REFERENCE_MEASURED:
+        chunk = int(max(10, min(250, 10 * (seconds_target - dt) / max(dt, 1e-3) / 4)))
+        while dt < seconds_target and done < 290 * nrep:      # stays inside the first episode
+            done += batch_run_policy(envs, policy, min(chunk, 290 - done // nrep), threads)
+            dt = time.perf_counter() - t0
+        sample = (f"{nrep} replicas x {done // nrep} steps of policy {policy} on the same workload after 700 first-fit steps "
+                  f"(network filled), OpenMP over replicas, {dt:.1f} s")
+    out = dict(value=done / dt, unit="env-steps/s", cores=threads, kind="port", sample=sample)
+    if workload in REFERENCE_MEASURED and policy == 0:
         # the chain GPU -> port (timed here) -> reference (timed in the build container: it cannot travel)
         out["reference_measured"] = dict(REFERENCE_MEASURED[workload], unit="env-steps/s",
                                          where="build container, Xeon 2.1 GHz, 8 vCPU (BASELINE.md §2)")
     return out
+
+
+def busy_frac(pmc, key, occ):
+    cyc, wave = pmc.get(key), pmc.get("wave_cycles_per_env_step")
+    if cyc is None or not wave or not occ.get("blocks_per_cu"):
+        return None
+    return cyc / (wave / (occ["blocks_per_cu"] / 4.0))
+
+
+POLICY_NAMES = {0: "fused first-fit policy+step", 1: "fused load_balancing_best_modulation policy+step",
+                2: "fused heuristic_highest_snr policy+step", 10: "fused heuristic_lowest_fragmentation policy+step"}
 
 
 def spawn_ranks(args):
@@ -148,6 +196,10 @@ def main():
     ap.add_argument("--workload", default="nsfnet320", choices=sorted(WORKLOADS))
     ap.add_argument("--steps-per-launch", type=int, default=250)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--policy", type=int, default=0,
+                    help="fused policy id (include/ongym.h): 0 first fit (the BASELINE metric), 1 load balancing, 2 highest SNR, "
+                         "10 lowest fragmentation have lean kernels; the others run the generic kernel")
+    ap.add_argument("--record", action="store_true", help="write the per-step record (the reference's `info`) for every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     if args.steps <= 0 or args.warmup < 0 or args.steps_per_launch <= 0:
@@ -169,7 +221,7 @@ def main():
     rehearse = os.environ.get("ONGYM_BENCH_REHEARSE") == "1"
     device = local_rank % torch.cuda.device_count() if rehearse else local_rank
     torch.cuda.set_device(device)
-    from optical_networking_gym._dist import init_process_group, reduce_run_statistics, shard_bounds
+    from optical_networking_gym._dist import gather_per_rank, init_process_group, reduce_run_statistics, shard_bounds
     # under torch.distributed.run (RANK set) the process group is always created, also for one rank
     backend = "gloo" if rehearse else "nccl"                                                          # "nccl" = RCCL
     dist = init_process_group(backend, device) if (world > 1 or "RANK" in os.environ) else None
@@ -187,15 +239,21 @@ def main():
     base, local_batch = shard_bounds(global_batch, rank, world)      # this rank's slice of the global replicas
     tables = build_tables(wl["topology"])
     env = BatchedQRMSAEnv(tables=tables, modulations=jocn_modulations(), batch_size=local_batch, device=device,
-                          num_spectrum_resources=wl["S"], capacity=wl["capacity"], episode_length=1000,
+                          io_device=bool(args.record), num_spectrum_resources=wl["S"], capacity=wl["capacity"], episode_length=1000,
                           auto_reset=True, load=wl["load"], bit_rate_selection="discrete", bit_rates=wl["bit_rates"])
     env.seed(args.seed, replica_base=base)
     env.reset()
 
+    rec_ptr = None
+    if args.record:     # the per-step records (the reference's `info`, qrmsa.pyx:996-1060) of one launch, kept in HBM
+        from optical_networking_gym import _native as nat
+        rec_buf = torch.empty(spl * local_batch * nat.STEP_DTYPE.itemsize, dtype=torch.uint8, device=f"cuda:{device}")
+        rec_ptr = rec_buf.data_ptr()
+
     def run(launches, timed):
         kernel_ms = 0.0
         for _ in range(launches):
-            env.step_policy(spl, record=False)
+            env.step_policy(spl, record=False, policy=args.policy, out_device_ptr=rec_ptr)
             if timed:
                 kernel_ms += env.last_kernel_ms()     # HIP events on the env's own stream
         return kernel_ms
@@ -221,8 +279,12 @@ def main():
     fields = ("total_steps", "total_accepted", "total_gn_evals", "total_interferer_terms", "total_paths_tried",
               "total_path_hops", "total_active_sum")
     delta = np.array([float(s1[f].sum() - s0[f].sum()) for f in fields], np.float64)
+    dt_rank, kernel_ms_rank = dt, kernel_ms
     delta, dt_max, kernel_ms = reduce_run_statistics(delta, dt, kernel_ms, dist,     # the only collective (RCCL)
                                                      device="cpu" if rehearse else "cuda")
+    # what the process group saw: its size and every rank's own rate and launch time (one all_gather, after the timed region)
+    per_rank = gather_per_rank([float(local_batch) * args.steps * spl / dt_rank, kernel_ms_rank / args.steps, float(local_batch)],
+                               dist, device="cpu" if rehearse else "cuda")
     stats_sum = dict(zip(fields, delta))
     expected = float(global_batch) * args.steps * spl
     if int(stats_sum["total_steps"]) != int(expected):
@@ -234,9 +296,14 @@ def main():
         avg_launch_s = kernel_ms / 1e3 / args.steps
         env_steps_per_launch = float(local_batch) * spl               # what ONE launch (on one GPU) processes
         achieved = bytes_step * env_steps_per_launch / avg_launch_s / 1e9
-        pmc = pmc_summary(args.workload)
+        pmc = pmc_summary(args.workload, args.policy)
+        occ = env.occupancy(args.policy)
         traffic = None
         issue = None
+        if pmc and pmc["stale"]:
+            print(f"bench.py: profiles/pmc_summary.json[{pmc_key(args.workload, args.policy)}] was collected on other kernel "
+                  f"sources ({pmc.get('kernel_source_sha')} != {kernel_source_hash()}): issue/traffic are marked stale",
+                  file=sys.stderr)
         if pmc:
             hbm_b = pmc.get("hbm_bytes_per_env_step")
             if hbm_b is not None:
@@ -251,7 +318,12 @@ def main():
                          "lds_wave_insts_per_env_step": pmc.get("lds_per_env_step"),
                          "smem_wave_insts_per_env_step": pmc.get("smem_per_env_step"),
                          "vmem_wave_insts_per_env_step": pmc.get("vmem_per_env_step"),
-                         "valu_busy_frac": pmc.get("valu_busy_frac"), "wait_any_frac": pmc.get("wait_any_frac"),
+                         # SQ_ACTIVE_INST_VALU / _SCA (x4 clocks) against the SIMD-clocks one env-step takes:
+                         # wave-cycles per env-step / resident waves per SIMD
+                         "valu_busy_frac": busy_frac(pmc, "valu_active_cycles_per_env_step", occ),
+                         "salu_busy_frac": busy_frac(pmc, "salu_active_cycles_per_env_step", occ),
+                         "wait_any_frac": pmc.get("wait_any_frac"),
+                         "stale": pmc["stale"], "kernel_source_sha": pmc.get("kernel_source_sha"),
                          "achieved": rate, "peak": VALU_ISSUE_PEAK, "unit": "VALU wave-insts/s",
                          "frac": rate / VALU_ISSUE_PEAK,
                          "salu_achieved": salu_rate, "salu_peak": SALU_ISSUE_PEAK,
@@ -266,19 +338,24 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"QRMSA {args.workload}: {tables.name} {tables.n_nodes}n/{tables.n_links}e, "
                                    f"S={wl['S']}, k=5, 6 modulations, load {wl['load']} Erlang, discrete bit rates "
-                                   f"{wl['bit_rates']}, episode_length 1000 with auto-reset, fused first-fit policy+step",
+                                   f"{wl['bit_rates']}, episode_length 1000 with auto-reset, "
+                                   f"{POLICY_NAMES.get(args.policy, f'fused policy {args.policy}+step')}"
+                                   f"{', step records written' if args.record else ''}",
+                       "policy": args.policy, "record": bool(args.record),
                        "batch_per_gpu": local_batch, "global_batch": global_batch,
                        "steps_per_launch": spl, "env_steps_per_bench_step": float(global_batch) * spl,
                        "fill_env_steps_per_replica_untimed": (fill_launches + args.warmup) * spl,
                        "parallelism": f"replica-sharded x{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "binding": "instruction issue (state is LDS-resident for a whole launch: see `issue`)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_stale": pmc["stale"] if (pmc and traffic is not None) else None,
                          "traffic_note": ("HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) per env-step from the "
                                           "tracked PMC passes x env-steps per launch; state is LDS-resident for a whole "
                                           "launch, so real traffic is far BELOW the algorithmic bytes and the HBM bound "
                                           "does not bind: see `issue`") if traffic is not None else None,
-                         "kernel": ("k_fast<M64,REC,ENT,WAVES> (csrc/ongym_fast.hpp)" if env.occupancy()["lean_kernel"]
-                                    else "k_run<uniform_alpha,codec,waves,first_fit> (csrc/ongym_device.hpp)"),
+                         "kernel": (f"k_fast<M64,REC,ENT,WAVES,TRACE,POL={args.policy}> (csrc/ongym_fast.hpp)" if occ["lean_kernel"]
+                                    else "k_run<uniform_alpha,codec,waves,policy> (csrc/ongym_device.hpp)"),
                          "avg_launch_ms": avg_launch_s * 1e3,
                          "algorithmic_bytes_per_env_step": bytes_step, "env_steps_per_launch": env_steps_per_launch,
                          **counters},
@@ -286,12 +363,17 @@ def main():
             "blocking_rate": 1.0 - stats_sum["total_accepted"] / stats_sum["total_steps"],
         }
         # the timed state must be the loaded network, whatever the CLI said
-        out["occupancy"] = env.occupancy()
+        out["occupancy"] = occ
+        # what the collective backend saw (n_gpus above comes from the launcher's WORLD_SIZE)
+        out["process_group"] = {"world_size": dist.get_world_size() if dist else 1,
+                                "backend": (dist.get_backend() if dist else None),
+                                "per_rank_value": [r[0] for r in per_rank], "per_rank_avg_launch_ms": [r[1] for r in per_rank],
+                                "per_rank_batch": [int(r[2]) for r in per_rank]}
         if rehearse:
             out["rehearsal"] = "ranks share GPUs, gloo reduction: plumbing check only, not a measurement"
         out["steady_state"] = bool(counters["mean_active_services"] >= 0.4 * wl["load"])
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(tables, wl, args.workload)
+            out["cpu_baseline"] = cpu_baseline(tables, wl, args.workload, args.policy)
         print(json.dumps(out), flush=True)
         if not out["steady_state"]:
             print("bench.py: mean active services far below the offered load: not the stated workload", file=sys.stderr)

@@ -45,3 +45,16 @@ def reduce_run_statistics(delta: np.ndarray, dt: float, kernel_ms: float, dist=N
     tt = torch.tensor([dt, kernel_ms], device=device, dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     return t.cpu().numpy(), float(tt[0]), float(tt[1])
+
+
+def gather_per_rank(values, dist=None, device: str = "cuda"):
+    """every rank's `values` (a short list of floats) on every rank, as a list of lists indexed by rank: lets the bench line
+    show what the process group really held (its size, each rank's own rate) instead of what the launcher's environment said."""
+    vals = [float(v) for v in values]
+    if dist is None:
+        return [vals]
+    import torch
+    mine = torch.tensor(vals, device=device, dtype=torch.float64)
+    out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [[float(x) for x in t.cpu()] for t in out]

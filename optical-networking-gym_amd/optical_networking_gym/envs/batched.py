@@ -115,8 +115,16 @@ class BatchedQRMSAEnv:
         self._check(self.lib.ongym_reset_episode_counters(self._h, mask.ctypes.data if mask is not None else None),
                     "ongym_reset_episode_counters")
 
-    def step_policy(self, nsteps: int = 1, record: bool = True, policy: int = nat.POLICY_FIRST_FIT):
-        """`nsteps` x {first-fit heuristic; step}. Returns STEP_DTYPE [nsteps, batch] when `record`, else None."""
+    def step_policy(self, nsteps: int = 1, record: bool = True, policy: int = nat.POLICY_FIRST_FIT,
+                    out_device_ptr: Optional[int] = None):
+        """`nsteps` x {heuristic `policy`; step}. Returns STEP_DTYPE [nsteps, batch] when `record`, else None.  With an
+        environment created with io_device=True, `out_device_ptr` is the address of a device buffer of nsteps * batch step
+        records (e.g. torch.Tensor.data_ptr()): the records stay on the device and the call returns without synchronising."""
+        if out_device_ptr is not None:
+            if not self.holder.struct.io_device:
+                raise ValueError("out_device_ptr needs an environment created with io_device=True")
+            self._check(self.lib.ongym_step_policy(self._h, policy, nsteps, C.c_void_p(out_device_ptr)), "ongym_step_policy")
+            return None
         out = np.zeros((nsteps, self.batch_size), nat.STEP_DTYPE) if record else None
         self._check(self.lib.ongym_step_policy(self._h, policy, nsteps, out.ctypes.data if record else None),
                     "ongym_step_policy")

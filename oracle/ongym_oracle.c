@@ -1306,3 +1306,13 @@ int64_t orc_batch_run_first_fit(orc_env **envs, int batch, int nsteps, int threa
     }
     return total;
 }
+
+/* The same for any policy id (bench.py --policy, the bench-shape parity tests of the lean policy kernels). */
+int64_t orc_batch_run_policy(orc_env **envs, int batch, int policy, int nsteps, int threads) {
+    int64_t total = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : total)
+    for (int b = 0; b < batch; b++) {
+        if (orc_run_policy(envs[b], policy, nsteps, 0) == 0) total += nsteps;
+    }
+    return total;
+}

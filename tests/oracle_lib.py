@@ -65,6 +65,8 @@ def lib():
         L.orc_run_first_fit.argtypes = [vp, C.c_int, vp]
         L.orc_batch_run_first_fit.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         L.orc_batch_run_first_fit.restype = C.c_int64
+        L.orc_batch_run_policy.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_batch_run_policy.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -204,3 +206,8 @@ class OracleEnv:
 def batch_run_first_fit(envs, nsteps: int, threads: int) -> int:
     arr = (C.c_void_p * len(envs))(*[e.h for e in envs])
     return lib().orc_batch_run_first_fit(arr, len(envs), nsteps, threads)
+
+
+def batch_run_policy(envs, policy: int, nsteps: int, threads: int) -> int:
+    arr = (C.c_void_p * len(envs))(*[e.h for e in envs])
+    return lib().orc_batch_run_policy(arr, len(envs), policy, nsteps, threads)

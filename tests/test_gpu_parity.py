@@ -10,6 +10,7 @@ from optical_networking_gym.envs.batched import BatchedQRMSAEnv, OngymError
 from oracle_lib import OracleEnv
 
 pytestmark = pytest.mark.gpu
+LEAN_POLICIES = (nat.POLICY_FIRST_FIT, nat.POLICY_LOAD_BALANCING, nat.POLICY_HIGHEST_SNR, nat.POLICY_LOWEST_FRAGMENTATION)
 
 GSNR_RTOL = 1e-9
 EXACT = ("action", "route", "modulation", "slot", "nslots", "accepted", "terminated", "retry", "flags", "active",
@@ -234,7 +235,7 @@ def test_randomised_configurations_vs_oracle(case, generic, monkeypatch):
 
 @pytest.mark.parametrize("pid", list(range(1, 12)))
 @pytest.mark.parametrize("case", range(3))
-def test_policies_randomised_configurations_vs_oracle(pid, case):
+def test_policies_randomised_configurations_vs_oracle(pid, case, monkeypatch):
     """Every fused policy other than first fit (ids 1..11) on two randomly drawn configurations each, after a first-fit
     warm-up: step records and grids equal to the oracle's."""
     rng = np.random.default_rng(7000 + 31 * pid + case)
@@ -252,14 +253,21 @@ def test_policies_randomised_configurations_vs_oracle(pid, case):
               bit_rate_selection="discrete", bit_rates=rates, auto_reset=True, episode_length=1000,
               launch_power_dbm=float(rng.uniform(-2, 3)), margin=float(rng.choice([0.0, 0.5])))
     holder = nat.ConfigHolder(tb, batch=B, **kw)
-    env = BatchedQRMSAEnv(tables=tb, batch_size=B, **kw)
-    env.seed(3 + case); env.reset()
-    env.step_policy(warm, record=False)
-    got = env.step_policy(steps, policy=pid)
+    want = []
     for r in range(B):
         o = OracleEnv(holder, replica=r)
         o.seed(3 + case); o.reset(); o.run_policy(0, warm)
-        assert_records_equal(got[:, r], o.run_policy(pid, steps), f"policy {pid} case {case}: {topo} S={S} k={k} rates={rates} replica {r}")
+        want.append(o.run_policy(pid, steps))
+    for generic in ((False, True) if pid in LEAN_POLICIES else (True,)):     # both kernels where a lean one exists
+        if generic:
+            monkeypatch.setenv("ONGYM_FORCE_GENERIC", "1")
+        env = BatchedQRMSAEnv(tables=tb, batch_size=B, **kw)
+        env.seed(3 + case); env.reset()
+        assert env.occupancy(pid)["lean_kernel"] == (not generic)
+        env.step_policy(warm, record=False)
+        got = env.step_policy(steps, policy=pid)
+        for r in range(B):
+            assert_records_equal(got[:, r], want[r], f"policy {pid} case {case} generic={generic}: {topo} S={S} k={k} rates={rates} replica {r}")
         np.testing.assert_array_equal(env.grid(r), o.grid())
 
 
@@ -738,14 +746,60 @@ def test_bench_shape_c3_c4_sampled_oracle(topo, S, load, capacity, B, blocks_per
         np.testing.assert_array_equal(a.grid(r), o.grid())
 
 
+@pytest.mark.parametrize("pid,B,steps,nsample", [(1, 65536, 1250, 32), (2, 16384, 750, 16), (10, 16384, 750, 16)])
+def test_bench_shape_lean_policies_sampled_oracle(pid, B, steps, nsample):
+    """The lean kernels of the other three JOCN heuristics (graph_load.py:116-125) at the shape `bench.py --policy` times them
+    (NSFNET-320, load 300, capacity 448, record=False, 250-step launches, whole episodes from the empty network): counters,
+    clocks, mean GSNR and grids of sampled replicas against the oracle's restatement of the heuristic (OpenMP over the
+    sample).  Semantics: heuristics.py:547-627 (load balancing), :272-328 (highest SNR), :330-414 (lowest fragmentation)."""
+    from oracle_lib import batch_run_policy
+    tb = golden_tables("nsfnet")
+    kw = dict(tables=tb, modulations=jocn_modulations(), batch_size=B, num_spectrum_resources=320, capacity=448,
+              load=300, bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), episode_length=1000)
+    a = BatchedQRMSAEnv(**kw); a.seed(1); a.reset()
+    assert a.occupancy(pid)["lean_kernel"]
+    for _ in range(steps // 250):
+        a.step_policy(250, record=False, policy=pid)
+    sa = a.stats()
+    assert not (sa["flags"] & nat.F_OVERFLOW).any() and sa["active"].max() < 448
+    assert (sa["total_steps"] == steps).all()
+    assert (sa["episode_services_accepted"] + sa["rejected"] == sa["episode_services_processed"] - 1).all()
+    holder = nat.ConfigHolder(tb, modulations=jocn_modulations(), num_spectrum_resources=320, batch=B, capacity=448,
+                              load=300, bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), episode_length=1000,
+                              auto_reset=True)
+    rng = np.random.default_rng(5 + pid)
+    sample = [0, 1, B - 1] + [int(x) for x in rng.integers(2, B - 1, nsample - 3)]
+    oracles = []
+    for r in sample:
+        o = OracleEnv(holder, replica=r)
+        o.seed(1); o.reset()
+        oracles.append(o)
+    import os
+    assert batch_run_policy(oracles, pid, steps, min(len(os.sched_getaffinity(0)), nsample)) == steps * nsample
+    for r, o in zip(sample, oracles):
+        check_state_invariants(a, tb, r, 320)
+        so = o.stats()
+        for f in ("services_accepted", "episode_services_accepted", "rejected", "bit_rate_provisioned", "active",
+                  "current_time", "last_episode_accepted", "last_service_blocking_rate"):
+            assert sa[r][f] == so[f], (pid, r, f)
+        np.testing.assert_array_equal(sa[r]["episode_modulation_hist"], so["episode_modulation_hist"])
+        if steps >= 1000:
+            assert sa[r]["last_mean_gsnr"] == pytest.approx(so["last_mean_gsnr"], rel=1e-9)
+        np.testing.assert_array_equal(a.grid(r), o.grid())
+
+
+@pytest.mark.parametrize("generic", [False, True], ids=["lean", "generic"])
 @pytest.mark.parametrize("tag", ["traj_nsfnet320_lb", "traj_nobeleu320_lb", "traj_nsfnet128_hsnr"])
-def test_other_fused_policies_vs_reference(tag):
+def test_other_fused_policies_vs_reference(tag, generic, monkeypatch):
     """fused load_balancing_best_modulation (heuristics.py:547-627) / heuristic_highest_snr (:272-328) against the
-    reference's captured runs."""
+    reference's captured runs, through the lean kernels (k_fast<..., POL>, csrc/ongym_fast.hpp) and the generic k_run."""
     meta, d = load_traj(tag)
     pid = {"load_balancing": nat.POLICY_LOAD_BALANCING, "highest_snr": nat.POLICY_HIGHEST_SNR}[meta["policy"]]
+    if generic:
+        monkeypatch.setenv("ONGYM_FORCE_GENERIC", "1")
     env = make_env(meta, auto_reset=True)
     env.set_requests(traj_requests(d))
+    assert env.occupancy(pid)["lean_kernel"] == (not generic)
     for _ in range(meta["initial_resets"]):
         env.reset()
     rec = env.step_policy(meta["n_steps"], policy=pid)[:, 0]
@@ -1007,7 +1061,7 @@ def test_misc_fused_policies_vs_oracle_random_traffic(pid):
 
 
 @pytest.mark.parametrize("pid,S,B,warm,steps,loads", [(10, 96, 5, 300, 200, (150, 330)), (11, 64, 4, 400, 120, (120, 260))])
-def test_scored_fused_policies_vs_oracle_random_traffic(pid, S, B, warm, steps, loads):
+def test_scored_fused_policies_vs_oracle_random_traffic(pid, S, B, warm, steps, loads, monkeypatch):
     """policy ids 10 (lowest fragmentation) and 11 (full MSCL) driving whole batched episodes (csrc/ongym_scored.hpp)
     against the oracle's restatements, which tests/test_oracle_golden.py pins to decisions captured from the reference
     (dec_nsfnet96_lf, dec_nsfnet64_mscl), after a first-fit warm-up that fills the network.  Bit-exact records: the float
@@ -1022,8 +1076,18 @@ def test_scored_fused_policies_vs_oracle_random_traffic(pid, S, B, warm, steps, 
                           num_spectrum_resources=S, capacity=512, episode_length=1000, auto_reset=True, load=100,
                           bit_rate_selection="discrete", bit_rates=(10, 40, 100), replica_load=loads)
     env.seed(9); env.reset()
+    assert env.occupancy(pid)["lean_kernel"] == (pid in LEAN_POLICIES)
     env.step_policy(warm, record=False)
     got = env.step_policy(steps, policy=pid)
+    if pid in LEAN_POLICIES:         # ... and the generic kernel gives the same records
+        monkeypatch.setenv("ONGYM_FORCE_GENERIC", "1")
+        env_g = BatchedQRMSAEnv(tables=golden_tables("nsfnet"), modulations=jocn_modulations(), batch_size=B,
+                                num_spectrum_resources=S, capacity=512, episode_length=1000, auto_reset=True, load=100,
+                                bit_rate_selection="discrete", bit_rates=(10, 40, 100), replica_load=loads)
+        env_g.seed(9); env_g.reset()
+        assert not env_g.occupancy(pid)["lean_kernel"]
+        env_g.step_policy(warm, record=False)
+        assert_records_equal(env_g.step_policy(steps, policy=pid), got, "generic vs lean")
     st = env.stats()
     rejected = qot = 0
     for r in range(B):

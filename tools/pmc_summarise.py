@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/pmc_summarise.py TAG WORKLOAD [--kernel SUBSTR] — turn the raw rocprofv3 output of tools/profile_bench.sh
+"""tools/pmc_summarise.py TAG KEY [--kernel SUBSTR]  (KEY = workload, or workload_pID for policy ID) — turn the raw rocprofv3 output of tools/profile_bench.sh
 (gpurun_out/prof_TAG/) into the tracked evidence under profiles/:
 
     profiles/TAG_bench.json          the un-profiled bench.py line
@@ -75,8 +75,14 @@ def main():
         if "SQ_WAIT_ANY" in avg:
             summ["wait_any_frac"] = avg["SQ_WAIT_ANY"] / avg["SQ_WAVE_CYCLES"]
         summ["wave_cycles_per_env_step"] = per["SQ_WAVE_CYCLES"] * 4
-    if "SQ_ACTIVE_INST_VALU" in avg and "SQ_BUSY_CYCLES" in avg:
+    if "SQ_ACTIVE_INST_VALU" in avg:
         summ["valu_active_cycles_per_env_step"] = per["SQ_ACTIVE_INST_VALU"] * 4
+    if "SQ_ACTIVE_INST_SCA" in avg:
+        summ["salu_active_cycles_per_env_step"] = per["SQ_ACTIVE_INST_SCA"] * 4
+    # ties the summary to the kernel sources it was measured on (bench.py marks it stale when they differ)
+    sys.path.insert(0, REPO)
+    import bench
+    summ["kernel_source_sha"] = bench.kernel_source_hash()
     pj = os.path.join(dst, "pmc_summary.json")
     allp = json.load(open(pj)) if os.path.exists(pj) else {}
     allp[workload] = summ
