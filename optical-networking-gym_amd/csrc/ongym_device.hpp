@@ -95,6 +95,9 @@ struct Params {
     // lean first-fit kernel (ongym_fast.hpp); NULL when the configuration is not eligible
     const void *path_rec;           // PathRec [P]
     const double *pair_tab2k;       // the pair table with a row pitch of 2048 entries: [tab_nmax][2048][2]
+    const double *pair_tabp;        // the same rows split by the parity of the distance: [tab_nmax][2][1024][2], entry (d & 1, d >> 1).
+                                    // Candidate centres of one format are two half slots apart: consecutive candidates then
+                                    // read consecutive 16-byte entries (full cache lines) instead of every other one
     const double *bit_rates, *bit_rate_cum, *node_cum;
     const double *path_len_norm;    // [P] observation(): (length - min link) / (max link - min link)
     const double *plogp;            // [S+1] (n/S)*log(n/S), n = 1..S: the Shannon-entropy terms of utils.pyx:61-79 (ongym_scored.hpp)

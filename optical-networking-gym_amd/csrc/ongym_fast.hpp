@@ -460,6 +460,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
     };
 
     const char __attribute__((address_space(1))) *const tab = (const char __attribute__((address_space(1))) *)P.pair_tab2k;
+    const char __attribute__((address_space(1))) *const tabp = (const char __attribute__((address_space(1))) *)P.pair_tabp;
 
     // LOWEST_FRAGMENTATION: score of a route = 0.33 * mean link entropy + 0.33 * cuts + 0.34 * rss over the route's link rows
     // (heuristics.py:375-384, utils.pyx:61-107), bit for bit — see lf_route_score (ongym_scored.hpp) for why that is possible;
@@ -544,225 +545,6 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         double ch_acc = 0.0, ch_ase = 0.0, ch_nli = 0.0;
         double best_acc = INFINITY;                 // HIGHEST_SNR: 1/GSNR of the best candidate so far
         bool lf_qot = false;
-        // the interferers of ONE route, cached in registers (lane j + 64 e = entry j of the list); `L` = their number
-        uint32_t e_c2k[ENT], e_key4[ENT];
-        double e_w1[ENT], e_pw2[ENT];
-        int e_terms = 0, L = -1, cache_path = -1, cache_terms = 0;
-        double ev_acc = 0.0, ev_ase = 0.0, ev_nli = 0.0;      // results of eval_one for the lane that counts
-
-        // centre, table row, summed link weights (Phi folded in) of running service `idx` as an interferer of the route
-        auto intf_of = [&](int idx, uint32_t mask_lo, uint32_t mask_hi, uint32_t &c2k, uint32_t &key4, double &w1o, double &pw2o) -> int {
-            const uint2 ab = rec[idx];
-            c2k = ab.y & 0x7FFu;
-            key4 = ((ab.y >> 14) & 0x1FFu) << 15;           // (n-1) * kTabPitch entries * 16 bytes
-            uint32_t mm = ab.x & mask_lo;
-            double w1 = 0.0, w2 = 0.0;
-            int terms = __popc(mm);
-            while (mm) { const int l = __ffs(mm) - 1; mm &= mm - 1; w1 += lw[2 * l]; w2 += lw[2 * l + 1]; }
-            if (M64) {
-                uint32_t mh = a2[idx] & mask_hi & 0xFFFFFu;
-                terms += __popc(mh);
-                while (mh) { const int l = 32 + __ffs(mh) - 1; mh &= mh - 1; w1 += lw[2 * l]; w2 += lw[2 * l + 1]; }
-            }
-            w1o = w1;
-            pw2o = phi[(ab.y >> 11) & 7u] * w2;
-            return terms;
-        };
-        // pass 1 of the GN model: interferers of the route -> LDS list -> registers (the first 64*ENT of them)
-        auto build_cache = [&](uint32_t mask_lo, uint32_t mask_hi) {
-            L = 0;
-            for (int base = 0; base < active; base += 2 * kWave) {
-                const int i0 = base + lane, i1 = i0 + kWave;
-                const int i1c = min(i1, C);          // beyond the table: the neutral entry
-                bool ov0 = (rec[i0].x & mask_lo) != 0, ov1 = (rec[i1c].x & mask_lo) != 0;    // unused entries: mask 0
-                if (M64) { ov0 |= (a2[i0] & mask_hi & 0xFFFFFu) != 0; ov1 |= (a2[i1c] & mask_hi & 0xFFFFFu) != 0; }
-                const uint64_t bal0 = __ballot(ov0), bal1 = __ballot(ov1);
-                const int n0 = __popcll((unsigned long long)bal0);
-                const int p0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal0, 0));
-                const int p1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal1, 0));
-                if (ov0) list[L + p0] = (uint16_t)i0;
-                if (ov1) list[L + n0 + p1] = (uint16_t)i1;
-                L += n0 + __popcll((unsigned long long)bal1);
-            }
-            wave_sync();
-            FSTAMP(3);
-            e_terms = 0;
-#pragma unroll
-            for (int e = 0; e < ENT; e++) {
-                const int j = lane + kWave * e;
-                e_c2k[e] = 0; e_key4[e] = 0; e_w1[e] = 0.0; e_pw2[e] = 0.0;
-                if (j < L) e_terms += intf_of(list[j], mask_lo, mask_hi, e_c2k[e], e_key4[e], e_w1[e], e_pw2[e]);
-            }
-            if (POL == ONGYM_POLICY_HIGHEST_SNR || POL == ONGYM_POLICY_LOWEST_FRAGMENTATION) {
-                int tt = e_terms;       // interferer-link terms of one evaluation on this route (statistics)
-                for (int base = kWave * ENT; base < L; base += kWave)
-                    if (base + lane < L) { uint32_t a_, b_; double c_, d_; tt += intf_of(list[base + lane], mask_lo, mask_hi, a_, b_, c_, d_); }
-                cache_terms = wave_sum_i32(tt);
-            }
-        };
-        // pass 2: 1/GSNR of ONE candidate (start `first`, width nn) with lanes over the interferers.  Every lane finishes the
-        // evaluation for ITS (bit rate, format) entry of the per-lane tables l_*; lane q is the one that counts.  Returns
-        // the decision of qot_ok; ev_acc (and ev_ase / ev_nli when records are written) hold lane q's values when it passes.
-        auto eval_one = [&](int first, int nn, int q, const PathRec &pr, double l_bw, double l_h, double l_nlic, double l_selfa,
-                            double l_lo, double l_hi) -> int {
-            const uint32_t c2 = (uint32_t)(2 * first + nn);
-            double part = 0.0;
-            {
-                TabPair t[ENT];
-#pragma unroll
-                for (int e = 0; e < ENT; e++) {
-                    const uint32_t adi = __builtin_amdgcn_sad_u16(e_c2k[e], c2, 0);       // |c2k - c2|, both < 2^11
-                    t[e] = load_pair(tab, e_key4[e] | (adi << 4));
-                }
-#pragma unroll
-                for (int e = 0; e < ENT; e++) part += t[e].x * e_w1[e] - t[e].y * e_pw2[e];
-            }
-            lane_terms += e_terms;
-            for (int base = kWave * ENT; base < L; base += kWave) {       // interferers beyond the register cache
-                const int j = base + lane;
-                if (j < L) {
-                    uint32_t c2k, key4;
-                    double w1, pw2;
-                    lane_terms += intf_of(list[j], pr.mask_lo, pr.mask_hi, c2k, key4, w1, pw2);
-                    const uint32_t adi = __builtin_amdgcn_sad_u16(c2k, c2, 0);
-                    const TabPair t = load_pair(tab, key4 | (adi << 4));
-                    part += t.x * w1 - t.y * pw2;
-                }
-            }
-            d_evals++;
-            const double tot = wave_sum(part);
-            const double fc = P.f0 + (P.slot_bw * first) + l_h;                  // envs/qrmsa.pyx:901-905
-            const double g_nli = l_nlic * (tot + pr.w1 * l_selfa);
-            const double g_ase = (l_bw * fc * pr.ase) * rp0;
-            const double acc = g_ase + g_nli;
-            int ok;
-            {
-                const uint64_t yes = __ballot(acc <= l_lo), no = __ballot(acc >= l_hi);
-                if ((yes >> q) & 1ull) ok = 1;
-                else if ((no >> q) & 1ull) ok = 0;
-                else {      // inside the 1e-9 band: the reference's own dB-domain expression (see qot_ok)
-                    const uint64_t db = __ballot(10.0 * log10(1.0 / acc) >= P.mod_thr[lane & 7] + *KC(&ge->margin));
-                    ok = (int)((db >> q) & 1ull);
-                }
-            }
-            if (ok) {
-                ev_acc = readlane_f64(acc, q);
-                if (REC) { ev_ase = readlane_f64(g_ase, q); ev_nli = readlane_f64(g_nli, q); }
-            }
-            return ok;
-        };
-        // HIGHEST_SNR / LOWEST_FRAGMENTATION: the set bits of `v` (run-AND words, lane w = word w) as ascending slot indices in
-        // dense lanes (xlist); returns their number
-        auto compact_starts = [&](uint32_t v) -> int {
-            int cnt = 0;
-            for (int i = 0; 2 * i < RW; i++) {
-                const uint32_t w0 = rl(v, 2 * i), w1 = rl(v, 2 * i + 1);
-                if (!(w0 | w1)) continue;
-                const int pre = __builtin_amdgcn_mbcnt_hi(w1, __builtin_amdgcn_mbcnt_lo(w0, 0));
-                const uint32_t mine = lane < 32 ? (w0 >> lane) : (w1 >> (lane - 32));
-                if (mine & 1u) xlist[cnt + pre] = (uint16_t)(64 * i + lane);
-                cnt += __popc(w0) + __popc(w1);
-            }
-            wave_sync();
-            return cnt;
-        };
-        // ... and their GN evaluation with LANES OVER THE CANDIDATES (two chunks of 64 per pass).  The route's interferers are
-        // staged in LDS 64 at a time (centre, table row, summed link weights); every lane then reads the same entry (a
-        // broadcast read, no v_readlane and no scalar registers) and each (interferer, chunk) costs |x - c_k|, one address
-        // op, one 16-byte gather and two FMAs, four interferers (eight gathers) in flight.  No validity test: a valid start
-        // never overlaps a running service on a shared link, so |x - c_k| > n_k; dead lanes read table entries that exist.
-        // Partial sums are lower bounds of 1/GSNR (no interferer term is negative, Params.ase_shortcut): a pass stops as soon
-        // as no candidate can stay below the acceptance limit — or, for HIGHEST_SNR, below the best candidate so far.
-        // HIGHEST_SNR keeps the best passing candidate (strictly smaller 1/GSNR: the first maximum wins, heuristics.py:316);
-        // LOWEST_FRAGMENTATION stops at the first that passes.
-        auto eval_cands = [&](int cnt, int nn, int m, int q, const PathRec &pr, int k, int path, uint64_t pmask, double l_nlic,
-                              double l_selfa, double l_lo, double l_hi) -> bool {
-            constexpr int NA = 2, TU = 4;
-            const double c_bw = P.slot_bw * nn, c_h = P.slot_bw * (nn / 2.0);
-            const double c_nlic = readlane_f64(l_nlic, q), c_self = pr.w1 * readlane_f64(l_selfa, q);
-            const double c_lo = readlane_f64(l_lo, q), c_hi = readlane_f64(l_hi, q);
-            for (int j0 = 0; j0 < cnt; j0 += NA * kWave) {
-                const bool two = j0 + kWave < cnt;          // the second chunk holds candidates (wave-uniform)
-                uint32_t ss[NA], xs[NA];
-                double f[NA], gase[NA];
-                bool live[NA];
-#pragma unroll
-                for (int a = 0; a < NA; a++) {
-                    const int j = j0 + a * kWave + lane;
-                    live[a] = j < cnt;
-                    ss[a] = live[a] ? (uint32_t)xlist[j] : 0u;
-                    xs[a] = 2u * ss[a] + (uint32_t)nn;
-                    f[a] = 0.0;
-                    const double fc = P.f0 + (P.slot_bw * (int)ss[a]) + c_h;           // envs/qrmsa.pyx:901-905
-                    gase[a] = (c_bw * fc * pr.ase) * rp0;
-                }
-                const double thr = POL == ONGYM_POLICY_HIGHEST_SNR ? fmin(c_hi, best_acc) : c_hi;
-                bool cut = false;
-                for (int base = 0; base < L && !cut; base += kWave) {
-                    {   // stage: lane j = interferer base + j (zero weights beyond the list)
-                        uint32_t c2k = 0, key4 = 0;
-                        double w1 = 0.0, pw2 = 0.0;
-                        if (base + lane < L) intf_of((int)list[base + lane], pr.mask_lo, pr.mask_hi, c2k, key4, w1, pw2);
-                        st_ck[lane] = make_uint2(c2k, key4);
-                        st_w[lane] = make_double2(w1, pw2);
-                    }
-                    wave_sync();
-                    const int ne = min(kWave, L - base);
-                    for (int t = 0; t < ne; t += TU) {
-                        uint2 ck[TU];
-                        double2 w[TU];
-#pragma unroll
-                        for (int u = 0; u < TU; u++) { ck[u] = st_ck[t + u]; w[u] = st_w[t + u]; }
-                        TabPair tp[TU][NA];
-#pragma unroll
-                        for (int u = 0; u < TU; u++)
-#pragma unroll
-                            for (int a = 0; a < NA; a++)
-                                if (a == 0 || two) tp[u][a] = load_pair(tab, ck[u].y | (__builtin_amdgcn_sad_u16(xs[a], ck[u].x, 0) << 4));
-#pragma unroll
-                        for (int u = 0; u < TU; u++)
-#pragma unroll
-                            for (int a = 0; a < NA; a++)
-                                if (a == 0 || two) f[a] += tp[u][a].x * w[u].x - tp[u][a].y * w[u].y;
-                        if ((t & 15) == 12 && base + t + TU < L) {      // every 16 interferers: can any candidate still matter?
-                            bool alive = live[0] && gase[0] + c_nlic * (f[0] + c_self) < thr;
-                            if (two) alive |= live[1] && gase[1] + c_nlic * (f[1] + c_self) < thr;
-                            if (!__ballot(alive)) { cut = true; break; }
-                        }
-                    }
-                    wave_sync();                            // the stage is rewritten by the next block
-                }
-#pragma unroll
-                for (int a = 0; a < NA; a++) {
-                    if (a > 0 && !two) break;
-                    d_evals += __popcll((unsigned long long)__ballot(live[a]));
-                    lane_terms += live[a] ? cache_terms : 0;
-                    if (cut) continue;
-                    const double g_nli = c_nlic * (f[a] + c_self);
-                    const double acc = gase[a] + g_nli;
-                    bool ok = live[a] && acc <= c_lo;
-                    if (live[a] && !ok && acc < c_hi) ok = 10.0 * log10(1.0 / acc) >= P.mod_thr[m] + margin;   // the 1e-9 band (qot_ok)
-                    const uint64_t okb = __ballot(ok);
-                    if (!okb) continue;
-                    if (POL == ONGYM_POLICY_HIGHEST_SNR) {
-                        const double v = ok ? acc : INFINITY;
-                        const double vmin = wave_min_f64(v);
-                        if (vmin < best_acc) {
-                            const int ln = __builtin_ctzll(__ballot(v == vmin));
-                            best_acc = vmin; ch_acc = vmin;
-                            ch_k = k; ch_m = m; ch_n = nn; ch_path = path; ch_mask = pmask; ch_slot = (int)rl(ss[a], ln);
-                            if (REC) { ch_ase = readlane_f64(gase[a], ln); ch_nli = readlane_f64(g_nli, ln); }
-                        }
-                    } else {
-                        const int ln = __builtin_ctzll(okb);
-                        ch_k = k; ch_m = m; ch_n = nn - 1; ch_path = path; ch_mask = pmask; ch_slot = (int)rl(ss[a], ln);
-                        return true;
-                    }
-                }
-            }
-            return false;
-        };
-
         // The routes of the request.  FIRST_FIT walks them in order and stops at the first that serves the request; the other
         // policies look at all of them, so their ids and records are fetched together (lane k = k-th route).
         int v_path = -1, v_rank = lane, nk = K;
@@ -857,7 +639,228 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             uint32_t runs = path_and(pmask);
             FSTAMP(1);
             int r_len = 1;
-            L = -1;
+            // (declared per route: nothing of the cache is live across routes or steps)
+            // the interferers of ONE route, cached in registers (lane j + 64 e = entry j of the list); `L` = their number
+            uint32_t e_c2k[ENT], e_key4[ENT];
+            double e_w1[ENT], e_pw2[ENT];
+            int e_terms = 0, L = -1, cache_terms = 0;
+            double ev_acc = 0.0, ev_ase = 0.0, ev_nli = 0.0;      // results of eval_one for the lane that counts
+
+            // centre, table row, summed link weights (Phi folded in) of running service `idx` as an interferer of the route
+            auto intf_of = [&](int idx, uint32_t mask_lo, uint32_t mask_hi, uint32_t &c2k, uint32_t &key4, double &w1o, double &pw2o) -> int {
+                const uint2 ab = rec[idx];
+                c2k = ab.y & 0x7FFu;
+                key4 = ((ab.y >> 14) & 0x1FFu) << 15;           // (n-1) * kTabPitch entries * 16 bytes
+                uint32_t mm = ab.x & mask_lo;
+                double w1 = 0.0, w2 = 0.0;
+                int terms = __popc(mm);
+                while (mm) { const int l = __ffs(mm) - 1; mm &= mm - 1; w1 += lw[2 * l]; w2 += lw[2 * l + 1]; }
+                if (M64) {
+                    uint32_t mh = a2[idx] & mask_hi & 0xFFFFFu;
+                    terms += __popc(mh);
+                    while (mh) { const int l = 32 + __ffs(mh) - 1; mh &= mh - 1; w1 += lw[2 * l]; w2 += lw[2 * l + 1]; }
+                }
+                w1o = w1;
+                pw2o = phi[(ab.y >> 11) & 7u] * w2;
+                return terms;
+            };
+            // pass 1 of the GN model: interferers of the route -> LDS list -> registers (the first 64*ENT of them)
+            auto build_cache = [&](uint32_t mask_lo, uint32_t mask_hi) {
+                L = 0;
+                for (int base = 0; base < active; base += 2 * kWave) {
+                    const int i0 = base + lane, i1 = i0 + kWave;
+                    const int i1c = min(i1, C);          // beyond the table: the neutral entry
+                    bool ov0 = (rec[i0].x & mask_lo) != 0, ov1 = (rec[i1c].x & mask_lo) != 0;    // unused entries: mask 0
+                    if (M64) { ov0 |= (a2[i0] & mask_hi & 0xFFFFFu) != 0; ov1 |= (a2[i1c] & mask_hi & 0xFFFFFu) != 0; }
+                    const uint64_t bal0 = __ballot(ov0), bal1 = __ballot(ov1);
+                    const int n0 = __popcll((unsigned long long)bal0);
+                    const int p0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal0, 0));
+                    const int p1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal1, 0));
+                    if (ov0) list[L + p0] = (uint16_t)i0;
+                    if (ov1) list[L + n0 + p1] = (uint16_t)i1;
+                    L += n0 + __popcll((unsigned long long)bal1);
+                }
+                wave_sync();
+                FSTAMP(3);
+                e_terms = 0;
+    #pragma unroll
+                for (int e = 0; e < ENT; e++) {
+                    const int j = lane + kWave * e;
+                    e_c2k[e] = 0; e_key4[e] = 0; e_w1[e] = 0.0; e_pw2[e] = 0.0;
+                    if (j < L) e_terms += intf_of(list[j], mask_lo, mask_hi, e_c2k[e], e_key4[e], e_w1[e], e_pw2[e]);
+                }
+                if (POL == ONGYM_POLICY_HIGHEST_SNR || POL == ONGYM_POLICY_LOWEST_FRAGMENTATION) {
+                    int tt = e_terms;       // interferer-link terms of one evaluation on this route (statistics)
+                    for (int base = kWave * ENT; base < L; base += kWave)
+                        if (base + lane < L) { uint32_t a_, b_; double c_, d_; tt += intf_of(list[base + lane], mask_lo, mask_hi, a_, b_, c_, d_); }
+                    cache_terms = wave_sum_i32(tt);
+                }
+            };
+            // pass 2: 1/GSNR of ONE candidate (start `first`, width nn) with lanes over the interferers.  Every lane finishes the
+            // evaluation for ITS (bit rate, format) entry of the per-lane tables l_*; lane q is the one that counts.  Returns
+            // the decision of qot_ok; ev_acc (and ev_ase / ev_nli when records are written) hold lane q's values when it passes.
+            auto eval_one = [&](int first, int nn, int q, const PathRec &pr, double l_bw, double l_h, double l_nlic, double l_selfa,
+                                double l_lo, double l_hi) -> int {
+                const uint32_t c2 = (uint32_t)(2 * first + nn);
+                double part = 0.0;
+                {
+                    TabPair t[ENT];
+    #pragma unroll
+                    for (int e = 0; e < ENT; e++) {
+                        const uint32_t adi = __builtin_amdgcn_sad_u16(e_c2k[e], c2, 0);       // |c2k - c2|, both < 2^11
+                        t[e] = load_pair(tab, e_key4[e] | (adi << 4));
+                    }
+    #pragma unroll
+                    for (int e = 0; e < ENT; e++) part += t[e].x * e_w1[e] - t[e].y * e_pw2[e];
+                }
+                lane_terms += e_terms;
+                for (int base = kWave * ENT; base < L; base += kWave) {       // interferers beyond the register cache
+                    const int j = base + lane;
+                    if (j < L) {
+                        uint32_t c2k, key4;
+                        double w1, pw2;
+                        lane_terms += intf_of(list[j], pr.mask_lo, pr.mask_hi, c2k, key4, w1, pw2);
+                        const uint32_t adi = __builtin_amdgcn_sad_u16(c2k, c2, 0);
+                        const TabPair t = load_pair(tab, key4 | (adi << 4));
+                        part += t.x * w1 - t.y * pw2;
+                    }
+                }
+                d_evals++;
+                const double tot = wave_sum(part);
+                const double fc = P.f0 + (P.slot_bw * first) + l_h;                  // envs/qrmsa.pyx:901-905
+                const double g_nli = l_nlic * (tot + pr.w1 * l_selfa);
+                const double g_ase = (l_bw * fc * pr.ase) * rp0;
+                const double acc = g_ase + g_nli;
+                int ok;
+                {
+                    const uint64_t yes = __ballot(acc <= l_lo), no = __ballot(acc >= l_hi);
+                    if ((yes >> q) & 1ull) ok = 1;
+                    else if ((no >> q) & 1ull) ok = 0;
+                    else {      // inside the 1e-9 band: the reference's own dB-domain expression (see qot_ok)
+                        const uint64_t db = __ballot(10.0 * log10(1.0 / acc) >= P.mod_thr[lane & 7] + *KC(&ge->margin));
+                        ok = (int)((db >> q) & 1ull);
+                    }
+                }
+                if (ok) {
+                    ev_acc = readlane_f64(acc, q);
+                    if (REC) { ev_ase = readlane_f64(g_ase, q); ev_nli = readlane_f64(g_nli, q); }
+                }
+                return ok;
+            };
+            // HIGHEST_SNR / LOWEST_FRAGMENTATION: the set bits of `v` (run-AND words, lane w = word w) as ascending slot indices in
+            // dense lanes (xlist); returns their number
+            auto compact_starts = [&](uint32_t v) -> int {
+                int cnt = 0;
+                for (int i = 0; 2 * i < RW; i++) {
+                    const uint32_t w0 = rl(v, 2 * i), w1 = rl(v, 2 * i + 1);
+                    if (!(w0 | w1)) continue;
+                    const int pre = __builtin_amdgcn_mbcnt_hi(w1, __builtin_amdgcn_mbcnt_lo(w0, 0));
+                    const uint32_t mine = lane < 32 ? (w0 >> lane) : (w1 >> (lane - 32));
+                    if (mine & 1u) xlist[cnt + pre] = (uint16_t)(64 * i + lane);
+                    cnt += __popc(w0) + __popc(w1);
+                }
+                wave_sync();
+                return cnt;
+            };
+            // ... and their GN evaluation with LANES OVER THE CANDIDATES (two chunks of 64 per pass).  The route's interferers are
+            // staged in LDS 64 at a time (centre, table row, summed link weights); every lane then reads the same entry (a
+            // broadcast read, no v_readlane and no scalar registers) and each (interferer, chunk) costs |x - c_k|, one address
+            // op, one 16-byte gather and two FMAs, four interferers (eight gathers) in flight.  No validity test: a valid start
+            // never overlaps a running service on a shared link, so |x - c_k| > n_k; dead lanes read table entries that exist.
+            // Partial sums are lower bounds of 1/GSNR (no interferer term is negative, Params.ase_shortcut): a pass stops as soon
+            // as no candidate can stay below the acceptance limit — or, for HIGHEST_SNR, below the best candidate so far.
+            // HIGHEST_SNR keeps the best passing candidate (strictly smaller 1/GSNR: the first maximum wins, heuristics.py:316);
+            // LOWEST_FRAGMENTATION stops at the first that passes.
+            auto eval_cands = [&](int cnt, int nn, int m, int q, const PathRec &pr, int k, int path, uint64_t pmask, double l_nlic,
+                                  double l_selfa, double l_lo, double l_hi) -> bool {
+                constexpr int NA = 2, TU = 4;
+                const double c_bw = P.slot_bw * nn, c_h = P.slot_bw * (nn / 2.0);
+                const double c_nlic = readlane_f64(l_nlic, q), c_self = pr.w1 * readlane_f64(l_selfa, q);
+                const double c_lo = readlane_f64(l_lo, q), c_hi = readlane_f64(l_hi, q);
+                for (int j0 = 0; j0 < cnt; j0 += NA * kWave) {
+                    const bool two = j0 + kWave < cnt;          // the second chunk holds candidates (wave-uniform)
+                    uint32_t ss[NA], xs[NA];
+                    double f[NA], gase[NA];
+                    bool live[NA];
+    #pragma unroll
+                    for (int a = 0; a < NA; a++) {
+                        const int j = j0 + a * kWave + lane;
+                        live[a] = j < cnt;
+                        ss[a] = live[a] ? (uint32_t)xlist[j] : 0u;
+                        xs[a] = 2u * ss[a] + (uint32_t)nn;
+                        f[a] = 0.0;
+                        const double fc = P.f0 + (P.slot_bw * (int)ss[a]) + c_h;           // envs/qrmsa.pyx:901-905
+                        gase[a] = (c_bw * fc * pr.ase) * rp0;
+                    }
+                    const double thr = POL == ONGYM_POLICY_HIGHEST_SNR ? fmin(c_hi, best_acc) : c_hi;
+                    bool cut = false;
+                    for (int base = 0; base < L && !cut; base += kWave) {
+                        {   // stage: lane j = interferer base + j (zero weights beyond the list)
+                            uint32_t c2k = 0, key4 = 0;
+                            double w1 = 0.0, pw2 = 0.0;
+                            if (base + lane < L) intf_of((int)list[base + lane], pr.mask_lo, pr.mask_hi, c2k, key4, w1, pw2);
+                            key4 |= ((c2k + (uint32_t)nn) & 1u) << 14;       // the parity half of the row: every candidate of the pass has x = 2s + nn
+                            st_ck[lane] = make_uint2(c2k, key4);
+                            st_w[lane] = make_double2(w1, pw2);
+                        }
+                        wave_sync();
+                        const int ne = min(kWave, L - base);
+                        for (int t = 0; t < ne; t += TU) {
+                            uint2 ck[TU];
+                            double2 w[TU];
+    #pragma unroll
+                            for (int u = 0; u < TU; u++) { ck[u] = st_ck[t + u]; w[u] = st_w[t + u]; }
+                            TabPair tp[TU][NA];
+    #pragma unroll
+                            for (int u = 0; u < TU; u++)
+    #pragma unroll
+                                for (int a = 0; a < NA; a++)
+                                    if (a == 0 || two)      // entry (d & 1, d >> 1) of the row, d = |x - c_k|
+                                        tp[u][a] = load_pair(tabp, ck[u].y | ((__builtin_amdgcn_sad_u16(xs[a], ck[u].x, 0) << 3) & 0xFFF0u));
+    #pragma unroll
+                            for (int u = 0; u < TU; u++)
+    #pragma unroll
+                                for (int a = 0; a < NA; a++)
+                                    if (a == 0 || two) f[a] = fma(tp[u][a].x, w[u].x, fma(-tp[u][a].y, w[u].y, f[a]));
+                            if ((t & 15) == 12 && base + t + TU < L) {      // every 16 interferers: can any candidate still matter?
+                                bool alive = live[0] && gase[0] + c_nlic * (f[0] + c_self) < thr;
+                                if (two) alive |= live[1] && gase[1] + c_nlic * (f[1] + c_self) < thr;
+                                if (!__ballot(alive)) { cut = true; break; }
+                            }
+                        }
+                        wave_sync();                            // the stage is rewritten by the next block
+                    }
+    #pragma unroll
+                    for (int a = 0; a < NA; a++) {
+                        if (a > 0 && !two) break;
+                        d_evals += __popcll((unsigned long long)__ballot(live[a]));
+                        lane_terms += live[a] ? cache_terms : 0;
+                        if (cut) continue;
+                        const double g_nli = c_nlic * (f[a] + c_self);
+                        const double acc = gase[a] + g_nli;
+                        bool ok = live[a] && acc <= c_lo;
+                        if (live[a] && !ok && acc < c_hi) ok = 10.0 * log10(1.0 / acc) >= P.mod_thr[m] + margin;   // the 1e-9 band (qot_ok)
+                        const uint64_t okb = __ballot(ok);
+                        if (!okb) continue;
+                        if (POL == ONGYM_POLICY_HIGHEST_SNR) {
+                            const double v = ok ? acc : INFINITY;
+                            const double vmin = wave_min_f64(v);
+                            if (vmin < best_acc) {
+                                const int ln = __builtin_ctzll(__ballot(v == vmin));
+                                best_acc = vmin; ch_acc = vmin;
+                                ch_k = k; ch_m = m; ch_n = nn; ch_path = path; ch_mask = pmask; ch_slot = (int)rl(ss[a], ln);
+                                if (REC) { ch_ase = readlane_f64(gase[a], ln); ch_nli = readlane_f64(g_nli, ln); }
+                            }
+                        } else {
+                            const int ln = __builtin_ctzll(okb);
+                            ch_k = k; ch_m = m; ch_n = nn - 1; ch_path = path; ch_mask = pmask; ch_slot = (int)rl(ss[a], ln);
+                            return true;
+                        }
+                    }
+                }
+                return false;
+            };
+
             while (feas) {
                 const int m = 31 - __builtin_clz(feas);            // best modulation first
                 feas &= ~(1u << m);
@@ -870,7 +873,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                 FSTAMP(2);
                 if (first < 0) continue;
                 if (POL == ONGYM_POLICY_HIGHEST_SNR && !((__ballot(lb < best_acc) >> q) & 1ull)) continue;   // best_acc may have improved
-                if (L < 0) { build_cache(pr.mask_lo, pr.mask_hi); cache_path = path; }
+                if (L < 0) build_cache(pr.mask_lo, pr.mask_hi);
                 FSTAMP(4);
                 if (POL == ONGYM_POLICY_HIGHEST_SNR) {
                     const int cnt = compact_starts(runs);
@@ -897,18 +900,17 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                     if (hit) break;
                 }
             }
+            if (POL == ONGYM_POLICY_LOWEST_FRAGMENTATION && ch_k >= 0) {
+                // `env.step(action)` evaluates the GN model itself at the width the format needs (the heuristic asked for one slot
+                // more): the reference raises ValueError if that fails (envs/qrmsa.pyx:925-929) — a fused episode rejects the
+                // request and flags it (as k_run does).  Same route: the interferer cache is the one just used.
+                const double s_bw = P.slot_bw * t_n, s_h = P.slot_bw * (t_n / 2.0);
+                if (eval_one(ch_slot, ch_n, 8 * cur_bi + ch_m, pr, s_bw, s_h, t_nlic, t_selfa, t_lim_lo, t_lim_hi)) {
+                    ch_acc = ev_acc; ch_ase = ev_ase; ch_nli = ev_nli;
+                } else { ch_k = -1; lf_qot = true; }
+                break;
+            }
             if (POL != ONGYM_POLICY_HIGHEST_SNR && ch_k >= 0) break;
-        }
-        if (POL == ONGYM_POLICY_LOWEST_FRAGMENTATION && ch_k >= 0) {
-            // `env.step(action)` evaluates the GN model itself at the width the format needs (the heuristic asked for one slot
-            // more): the reference raises ValueError if that fails (envs/qrmsa.pyx:925-929) — a fused episode rejects the request
-            // and flags it (as k_run does)
-            const PathRec pr = load_path_rec(path_recs, ch_path);
-            if (cache_path != ch_path) { build_cache(pr.mask_lo, pr.mask_hi); cache_path = ch_path; }
-            const double s_bw = P.slot_bw * t_n, s_h = P.slot_bw * (t_n / 2.0);
-            if (eval_one(ch_slot, ch_n, 8 * cur_bi + ch_m, pr, s_bw, s_h, t_nlic, t_selfa, t_lim_lo, t_lim_hi)) {
-                ch_acc = ev_acc; ch_ase = ev_ase; ch_nli = ev_nli;
-            } else { ch_k = -1; lf_qot = true; }
         }
 
         // ================= step (envs/qrmsa.pyx:838-1065) ==============================================================

@@ -491,7 +491,7 @@ static int build(ongym_env *env, const ongym_config *c) {
     // expressions. nk range: the largest slot count the configured traffic can produce (anything larger, e.g. from a
     // replayed trace, is computed on the fly by the kernel).
     P.pair_tab = nullptr; P.tab_nmax = 0; P.tab_stride = 2 * c->n_slots + 1;
-    P.path_rec = nullptr; P.pair_tab2k = nullptr;
+    P.path_rec = nullptr; P.pair_tab2k = nullptr; P.pair_tabp = nullptr;
     std::vector<double2> host_tab;
     if (uniform) {
         double max_rate = 0.0;
@@ -566,6 +566,14 @@ static int build(ongym_env *env, const ongym_config *c) {
                 t2[((size_t)nk * kTabPitch + d) * 2 + 1] = host_tab[(size_t)nk * P.tab_stride + d].y;
             }
         if ((rc = upload(env, t2.data(), t2.size(), &P.pair_tab2k))) return rc;
+        std::vector<double> t3((size_t)P.tab_nmax * kTabPitch * 2, 0.0);
+        for (int nk = 0; nk < P.tab_nmax; nk++)
+            for (int d = 0; d < P.tab_stride; d++) {
+                const size_t e = (size_t)nk * kTabPitch + (size_t)(d & 1) * (kTabPitch / 2) + (size_t)(d >> 1);
+                t3[e * 2] = host_tab[(size_t)nk * P.tab_stride + d].x;
+                t3[e * 2 + 1] = host_tab[(size_t)nk * P.tab_stride + d].y;
+            }
+        if ((rc = upload(env, t3.data(), t3.size(), &P.pair_tabp))) return rc;
     }
     // ---- lean first-fit kernel (ongym_fast.hpp): eligibility and its path table ----
     {

@@ -211,7 +211,15 @@ def _declare(lib):
     lib.ongym_query_request.argtypes = [vp, C.c_int32, vp]
     lib.ongym_stats_get.argtypes = [vp, vp]
     lib.ongym_query_occupancy.argtypes = [vp, vp, vp, vp]
+    if os.environ.get("ONGYM_HIP_LIB") and not hasattr(lib, "ongym_query_occupancy_policy"):
+        # an older experiment build named by ONGYM_HIP_LIB (tools/ab_bench.py): first fit only
+        lib.ongym_query_occupancy_policy = lambda h, policy, nb, lds, lean: lib.ongym_query_occupancy(h, nb, lds, lean)
+        return _declare_tail(lib, vp, skip=("ongym_query_occupancy_policy",))
     lib.ongym_query_occupancy_policy.argtypes = [vp, C.c_int32, vp, vp, vp]
+    _declare_tail(lib, vp)
+
+
+def _declare_tail(lib, vp, skip=()):
     lib.ongym_sync.argtypes = [vp]
     lib.ongym_last_kernel_ms.argtypes = [vp]
     lib.ongym_last_kernel_ms.restype = C.c_double
@@ -223,7 +231,8 @@ def _declare(lib):
                  "ongym_step_actions", "ongym_policy_actions", "ongym_observe", "ongym_query_available", "ongym_query_gsnr", "ongym_query_gsnr_many", "ongym_query_moves",
                  "ongym_query_grid", "ongym_query_services", "ongym_query_request", "ongym_stats_get", "ongym_sync",
                  "ongym_abi_version", "ongym_sizeof", "ongym_query_candidates", "ongym_query_path_free", "ongym_observe", "ongym_query_occupancy", "ongym_query_occupancy_policy"):
-        getattr(lib, name).restype = C.c_int32
+        if name not in skip:
+            getattr(lib, name).restype = C.c_int32
 
 
 EXPORTED_SYMBOLS = (
