@@ -304,6 +304,14 @@ int ongym_query_occupancy(ongym_env *env, int32_t *blocks_per_cu, int32_t *lds_b
  * (examples/JOCN_Benchmark_2024/graph_load.py:116-125). */
 int ongym_query_occupancy_policy(ongym_env *env, int32_t policy, int32_t *blocks_per_cu, int32_t *lds_bytes, int32_t *lean_kernel);
 int ongym_sync(ongym_env *env);
+/* Run every later call of this environment on the CALLER's HIP stream (a hipStream_t passed as void *, e.g. PyTorch-ROCm's
+ * torch.cuda.current_stream().cuda_stream) instead of the environment's own: the environment's launches are then ordered with
+ * the caller's kernels on that stream and an RL loop (observe -> policy network -> step) needs no host synchronisation
+ * between them.  use_own != 0 returns to the environment's own stream (hip_stream is then ignored); with use_own == 0 a NULL
+ * hip_stream is HIP's default (null) stream, which is what PyTorch's default current stream is.  The call first drains the
+ * stream used so far.  The caller keeps ownership of its stream and must keep it alive while it is set.  (The reference's
+ * counterpart is the implicit ordering of a single Python thread: wrappers/qrmsa_gym.py:45-59.) */
+int ongym_set_stream(ongym_env *env, void *hip_stream, int32_t use_own);
 /* Device time (ms, HIP events on the env's stream) of the most recent step launch; <0 if none. */
 double ongym_last_kernel_ms(ongym_env *env);
 const char *ongym_last_error(ongym_env *env);

@@ -729,7 +729,8 @@ int ongym_create(const ongym_config *cfg, ongym_env **out) {
     int rc = 0;
     do {
         if (hipSetDevice(cfg->device) != hipSuccess) { env->err = "hipSetDevice failed"; rc = ONGYM_E_HIP; break; }
-        if (hipStreamCreateWithFlags(&env->stream, hipStreamNonBlocking) != hipSuccess) { env->err = "hipStreamCreate failed"; rc = ONGYM_E_HIP; break; }
+        if (hipStreamCreateWithFlags(&env->own_stream, hipStreamNonBlocking) != hipSuccess) { env->err = "hipStreamCreate failed"; rc = ONGYM_E_HIP; break; }
+        env->stream = env->own_stream;
         if (hipEventCreate(&env->ev0) != hipSuccess || hipEventCreate(&env->ev1) != hipSuccess) { env->err = "hipEventCreate failed"; rc = ONGYM_E_HIP; break; }
         rc = build(env, cfg);
     } while (0);
@@ -751,7 +752,7 @@ void ongym_destroy(ongym_env *env) {
     if (env->d_out) (void)hipFree(env->d_out);
     if (env->ev0) (void)hipEventDestroy(env->ev0);
     if (env->ev1) (void)hipEventDestroy(env->ev1);
-    if (env->stream) (void)hipStreamDestroy(env->stream);
+    if (env->own_stream) (void)hipStreamDestroy(env->own_stream);      // a caller's stream (ongym_set_stream) is the caller's
     delete env;
 }
 
@@ -804,6 +805,15 @@ int ongym_sync(ongym_env *env) {
     if (!env) return ONGYM_E_ARG;
     HIP_TRY(env, hipSetDevice(env->cfg.device));
     HIP_TRY(env, hipStreamSynchronize(env->stream));
+    return ONGYM_OK;
+}
+
+int ongym_set_stream(ongym_env *env, void *hip_stream, int32_t use_own) {
+    if (!env) return ONGYM_E_ARG;
+    HIP_TRY(env, hipSetDevice(env->cfg.device));
+    HIP_TRY(env, hipStreamSynchronize(env->stream));        // nothing of this environment is in flight on the old stream
+    env->stream = use_own ? env->own_stream : static_cast<hipStream_t>(hip_stream);
+    env->timed = false;                                     // the events were recorded on the old stream
     return ONGYM_OK;
 }
 

@@ -14,7 +14,8 @@ struct ongym_env {
     ongym_config cfg{};
     Params P{};
     Params *d_P = nullptr;          // device copy read by the kernels (scalar loads); refreshed by push_params
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // the stream every call runs on: own_stream, or the caller's (ongym_set_stream)
+    hipStream_t own_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     size_t lds = 0;

@@ -58,3 +58,23 @@ def gather_per_rank(values, dist=None, device: str = "cuda"):
     out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(out, mine)
     return [[float(x) for x in t.cpu()] for t in out]
+
+
+def allreduce_mean_gradients(params, dist=None):
+    """Data-parallel learner step over env shards (BASELINE config 5: the reference feeds ONE MaskablePPO learner from 14
+    SubprocVecEnv workers, examples/ONDM_2025/train_multi_masked_ppo.py:410-458; here every rank steps its own shard of
+    the replicas and owns a copy of the learner): the gradients of all parameters travel in ONE flat bucket through ONE
+    all-reduce (RCCL over xGMI on the GPUs, gloo in the CPU tests) and are averaged over the ranks, so every rank applies
+    the same update.  xGMI rings are per-link bound: one ~20 MB bucket instead of one collective per tensor."""
+    params = [p for p in params if p.grad is not None]
+    if dist is None or not params:
+        return
+    import torch
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    dist.all_reduce(flat)
+    flat /= dist.get_world_size()
+    off = 0
+    for p in params:
+        n = p.grad.numel()
+        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        off += n

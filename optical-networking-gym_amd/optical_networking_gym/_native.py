@@ -221,6 +221,9 @@ def _declare(lib):
 
 def _declare_tail(lib, vp, skip=()):
     lib.ongym_sync.argtypes = [vp]
+    if hasattr(lib, "ongym_set_stream"):
+        lib.ongym_set_stream.argtypes = [vp, vp, C.c_int32]
+        lib.ongym_set_stream.restype = C.c_int32
     lib.ongym_last_kernel_ms.argtypes = [vp]
     lib.ongym_last_kernel_ms.restype = C.c_double
     lib.ongym_last_error.argtypes = [vp]
@@ -239,7 +242,7 @@ EXPORTED_SYMBOLS = (
     "ongym_create", "ongym_destroy", "ongym_seed", "ongym_seed_base", "ongym_set_requests", "ongym_reset", "ongym_reset_episode_counters", "ongym_step_policy",
     "ongym_step_actions", "ongym_policy_actions", "ongym_observe", "ongym_query_available", "ongym_query_gsnr", "ongym_query_gsnr_many", "ongym_query_moves", "ongym_query_grid",
     "ongym_query_services", "ongym_query_request", "ongym_query_candidates", "ongym_query_path_free",
-    "ongym_stats_get", "ongym_sync", "ongym_last_kernel_ms", "ongym_query_occupancy", "ongym_query_occupancy_policy",
+    "ongym_stats_get", "ongym_sync", "ongym_set_stream", "ongym_last_kernel_ms", "ongym_query_occupancy", "ongym_query_occupancy_policy",
     "ongym_last_error", "ongym_abi_version", "ongym_sizeof")
 
 

@@ -226,6 +226,14 @@ class BatchedQRMSAEnv:
                     "ongym_query_occupancy_policy")
         return dict(blocks_per_cu=nb.value, lds_bytes=lds.value, lean_kernel=bool(lean.value))
 
+    def set_stream(self, stream_handle: Optional[int]):
+        """Run this environment's launches on the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream); None
+        returns to the environment's own stream.  See ongym_set_stream (include/ongym.h)."""
+        if stream_handle is None:
+            self._check(self.lib.ongym_set_stream(self._h, None, 1), "ongym_set_stream")
+        else:       # 0 is HIP's default (null) stream: torch's default current stream
+            self._check(self.lib.ongym_set_stream(self._h, C.c_void_p(int(stream_handle)), 0), "ongym_set_stream")
+
     def sync(self):
         self._check(self.lib.ongym_sync(self._h), "ongym_sync")
 

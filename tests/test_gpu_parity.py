@@ -1149,3 +1149,64 @@ def test_long_wide_sweep_final_state_vs_oracle():
         np.testing.assert_array_equal(env.grid(r), o.grid())
         blocked += int(so["total_steps"] - so["total_accepted"])
     assert blocked > 50000          # the sweep does reach heavily blocked regimes
+
+
+def test_caller_stream_equals_own_stream():
+    """ongym_set_stream: observe -> torch ops -> step on torch's current stream with NO host synchronisation in between gives
+    the records of the same loop run on the environment's own stream with a synchronisation after every call."""
+    import torch
+    tb = golden_tables("nsfnet")
+    B, steps = 256, 40
+    kw = dict(tables=tb, modulations=jocn_modulations(), batch_size=B, num_spectrum_resources=320, capacity=448, load=300,
+              bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), episode_length=1000, io_device=True)
+    dev = torch.device("cuda", 0)
+    out = []
+    for shared in (False, True):
+        env = BatchedQRMSAEnv(**kw)
+        c = env.holder.struct
+        obs = torch.empty((B, 3 + c.k_paths + c.k_paths * c.n_mods_consider * 12), dtype=torch.float32, device=dev)
+        mask = torch.empty((B, c.k_paths * c.n_mods_consider * c.n_slots + 1), dtype=torch.uint8, device=dev)
+        actions = torch.empty(B, dtype=torch.int32, device=dev)
+        recs = torch.empty((steps, B, nat.STEP_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        env.seed(3); env.reset()
+        env.step_policy(300, record=False); env.sync()
+        stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(stream):
+            if shared:
+                env.set_stream(stream.cuda_stream)
+            for i in range(steps):
+                env._check(env.lib.ongym_observe(env._h, obs.data_ptr(), mask.data_ptr()), "observe")
+                if not shared:
+                    env.sync()
+                # the lowest allowed action of every replica (deterministic), computed by torch on the same stream
+                actions.copy_(torch.argmax(mask, dim=1))
+                if not shared:
+                    stream.synchronize()
+                env._check(env.lib.ongym_step_actions(env._h, actions.data_ptr(), recs[i].data_ptr()), "step")
+                if not shared:
+                    env.sync()
+            stream.synchronize()
+            if shared:
+                env.set_stream(None)
+        out.append(recs.cpu().numpy().view(nat.STEP_DTYPE).reshape(steps, B).copy())
+        assert out[-1]["accepted"].mean() > 0.5
+    for f in nat.STEP_DTYPE.names:       # (field by field: the records' padding bytes are not written)
+        assert np.array_equal(out[0][f], out[1][f]), f
+    # ... and on the DEFAULT stream (handle 0), which is what torch.cuda.current_stream() is unless the caller changed it
+    env = BatchedQRMSAEnv(**kw)
+    env.seed(3); env.reset(); env.step_policy(300, record=False); env.sync()
+    assert torch.cuda.current_stream().cuda_stream == 0
+    env.set_stream(torch.cuda.current_stream().cuda_stream)
+    c = env.holder.struct
+    obs = torch.empty((B, 3 + c.k_paths + c.k_paths * c.n_mods_consider * 12), dtype=torch.float32, device=dev)
+    mask = torch.empty((B, c.k_paths * c.n_mods_consider * c.n_slots + 1), dtype=torch.uint8, device=dev)
+    actions = torch.empty(B, dtype=torch.int32, device=dev)
+    recs = torch.empty((steps, B, nat.STEP_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    for i in range(steps):
+        env._check(env.lib.ongym_observe(env._h, obs.data_ptr(), mask.data_ptr()), "observe")
+        actions.copy_(torch.argmax(mask, dim=1))
+        env._check(env.lib.ongym_step_actions(env._h, actions.data_ptr(), recs[i].data_ptr()), "step")
+    torch.cuda.synchronize()
+    got = recs.cpu().numpy().view(nat.STEP_DTYPE).reshape(steps, B)
+    for f in nat.STEP_DTYPE.names:
+        assert np.array_equal(got[f], out[0][f]), f

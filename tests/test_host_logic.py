@@ -201,6 +201,60 @@ def test_two_rank_statistics_reduction_gloo(tmp_path):
     assert got["dt_max"] == 2.0 and got["k_ms"] == 20.0
 
 
+_GRAD_WORKER = r'''
+import json, os, sys
+sys.path[:0] = [%r]
+import torch, torch.distributed as dist
+from optical_networking_gym._dist import allreduce_mean_gradients, gather_per_rank, init_process_group
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+init_process_group("gloo")
+torch.manual_seed(0)                        # same initial weights on every rank, as tools/bench_rl.py --learner
+net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+head = torch.nn.Linear(3, 1)                # a parameter group without gradient on this step must be skipped, not crash
+params = list(net.parameters()) + list(head.parameters())
+opt = torch.optim.SGD(list(net.parameters()), lr=0.1)
+x = torch.arange(24, dtype=torch.float32).reshape(4, 6) * (rank + 1) / 10      # every rank sees its own shard of the batch
+loss = net(x).pow(2).mean()
+loss.backward()
+own = [p.grad.clone() for p in net.parameters()]
+allreduce_mean_gradients(params, dist)
+opt.step()
+per_rank = gather_per_rank([float(rank), float(sum(g.sum() for g in own))], dist, device="cpu")
+if rank == 0:
+    print(json.dumps(dict(grads=[p.grad.reshape(-1).tolist() for p in net.parameters()],
+                          weights=[p.detach().reshape(-1).tolist() for p in net.parameters()], per_rank=per_rank)))
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gradient_allreduce_gloo(tmp_path):
+    """the data-parallel learner of tools/bench_rl.py --gpus N: one flat bucket, one all-reduce, mean over the ranks, the
+    same update everywhere (world_size 2 on gloo; on the GPUs the same call runs over RCCL)."""
+    import torch
+    script = tmp_path / "grad_worker.py"
+    script.write_text(_GRAD_WORKER % os.path.join(REPO, "optical-networking-gym_amd"))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
+                         capture_output=True, text=True, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    # ground truth in one process: the mean of the two ranks' gradients, one SGD step
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    grads = []
+    for rank in range(2):
+        net.zero_grad()
+        x = torch.arange(24, dtype=torch.float32).reshape(4, 6) * (rank + 1) / 10
+        net(x).pow(2).mean().backward()
+        grads.append([p.grad.clone() for p in net.parameters()])
+    for i, p in enumerate(net.parameters()):
+        mean = (grads[0][i] + grads[1][i]) / 2
+        np.testing.assert_allclose(got["grads"][i], mean.reshape(-1).numpy(), rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(got["weights"][i], (p.detach() - 0.1 * mean).reshape(-1).numpy(), rtol=1e-6, atol=1e-8)
+    assert [r[0] for r in got["per_rank"]] == [0.0, 1.0]
+    assert got["per_rank"][0][1] != got["per_rank"][1][1]       # each rank really had its own gradients before the reduction
+
+
 # ---- the reference's own unit tests, restated (tests/test_utils.py, tests/test_rmsa.py of the reference) -----------------
 def test_span_link_and_rmsa_plumbing():
     from optical_networking_gym.envs.rmsa import RMSAEnv
