@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ONGYM_ABI_VERSION 2
+#define ONGYM_ABI_VERSION 3
 
 enum {
     ONGYM_OK = 0,
@@ -132,6 +132,11 @@ typedef struct ongym_config {
      * (action codec qrmsa.pyx:801-834, heuristics.py:36-54); ongym_observe then first finds max_modulation_idx like
      * get_max_modulation_index (qrmsa.pyx:543-581) and reports that window (:712-717). */
     int32_t n_mods_consider;
+    /* Width that get_number_slots divides by (qrmsa.pyx:1198-1205), in the unit of channel_width; 0 = channel_width itself.
+     * The reference's `bands` argument (qrmsa.pyx:417-425; passed by graph_launch_power.py:102) makes get_number_slots use the
+     * C band's width in Hz - every service then needs ONE slot (quirk Q9) - while observation() and step() keep computing
+     * frequencies with channel_width (qrmsa.pyx:606-610, 678): the two widths are separate fields here. */
+    double nslots_channel_width;
 } ongym_config;
 
 /* One service request; replaces the fields drawn in QRMSAEnv._next_service (qrmsa.pyx:1079-1101). */

@@ -72,6 +72,7 @@ struct Params {
     int ase_shortcut;   // 1: every interferer term of the NLI sum is provably >= 0 (checked on the host at create)
     int req_mode;
     double f0, slot_bw, channel_width, mean_holding;
+    double nslots_width;            // what get_number_slots divides by: channel_width, or the band's width when `bands` is set (quirk Q9)
     float mean_holding_f, pad_f;    // (float)mean_holding
     const int32_t *nreq_tab;        // [n_bit_rates*8] slots needed per (discrete bit rate, modulation)
     const double *req_coef;         // [n_bit_rates*8][2] (nli_coef[n], self_asinh[n]) of that slot count (0 if n is not in [1, S])
@@ -1108,7 +1109,7 @@ __device__ __forceinline__ void draw_next(Ctx &c) {
     } else {
         int nr = 0;
         if (c.lane < P.n_mods) {
-            nr = (int)ceil((double)br / ((double)P.mod_se[c.lane] * P.channel_width));
+            nr = (int)ceil((double)br / ((double)P.mod_se[c.lane] * P.nslots_width));
             c.nreq[c.lane] = nr;
         }
         set_request_coefs(c, nr, c.rp[1]);
@@ -2049,7 +2050,7 @@ __device__ __forceinline__ void load_state(Ctx &c) {
     {
         int nr = 0;
         if (c.lane < P.n_mods) {
-            nr = (int)ceil((double)c.e->cur_br / ((double)P.mod_se[c.lane] * P.channel_width));
+            nr = (int)ceil((double)c.e->cur_br / ((double)P.mod_se[c.lane] * P.nslots_width));
             c.nreq[c.lane] = nr;
         }
         set_request_coefs(c, nr, c.e->launch_power * c.e->launch_power);

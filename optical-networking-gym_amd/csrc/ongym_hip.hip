@@ -400,6 +400,7 @@ static int build(ongym_env *env, const ongym_config *c) {
     P.n_defrag_services = c->n_defrag_services;
     if (c->defragmentation && c->n_defrag_services < 0) return fail_arg(env, "n_defrag_services must be >= 0");
     P.f0 = c->frequency_start; P.slot_bw = c->slot_bandwidth; P.channel_width = c->channel_width;
+    P.nslots_width = c->nslots_channel_width > 0 ? c->nslots_channel_width : c->channel_width;
     P.mean_holding = c->mean_holding_time;
     P.max_bit_rate = c->max_bit_rate;
     if (c->bit_rate_mode == 0) env->cfg_bit_rates.assign(c->bit_rates, c->bit_rates + c->n_bit_rates);
@@ -457,7 +458,7 @@ static int build(ongym_env *env, const ongym_config *c) {
         for (int b = 0; b < c->n_bit_rates; b++)
             for (int m = 0; m < M; m++)
                 nreq_tab[(size_t)b * kMaxMods + m] =
-                    (int32_t)std::ceil((double)(float)c->bit_rates[b] / ((double)c->mod_se[m] * c->channel_width));
+                    (int32_t)std::ceil((double)(float)c->bit_rates[b] / ((double)c->mod_se[m] * P.nslots_width));
     // ASE-only rejection is exact iff no interferer term asinh(u)-asinh(v) - Phi*(5/3)*(Bk/|df|)*(l_eff/L) of
     // core/osnr.pyx:68-93 can be negative: scan the whole discrete domain (slot counts x centre distances in half
     // slots x modulation formats x distinct link classes) once.
@@ -499,7 +500,7 @@ static int build(ongym_env *env, const ongym_config *c) {
         else max_rate = (double)c->bit_rate_hi;
         int min_se = 6;
         for (int m = 0; m < M; m++) min_se = std::min(min_se, (int)c->mod_se[m]);
-        int nmax = (int)std::ceil(max_rate / ((double)min_se * c->channel_width));
+        int nmax = (int)std::ceil(max_rate / ((double)min_se * P.nslots_width));
         nmax = std::max(1, std::min(nmax, c->n_slots));
         size_t entries = (size_t)nmax * P.tab_stride;
         if (entries * sizeof(double2) <= (size_t)16 << 20) {

@@ -12,7 +12,7 @@ import numpy as np
 
 from ._tables import StaticTables, cumulative, modulation_arrays
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(os.path.dirname(PKG_DIR), "csrc")
 HIP_LIB_PATH = os.path.join(CSRC_DIR, "libongym_hip.so")
@@ -47,6 +47,7 @@ class OngymConfig(C.Structure):
         ("replica_launch_power_w", _f64p), ("replica_load", _f64p), ("replica_margin", _f64p),
         ("path_len_norm", _f64p), ("max_bit_rate", C.c_double),
         ("track_service_ids", C.c_int32), ("n_mods_consider", C.c_int32),
+        ("nslots_channel_width", C.c_double),
     ]
 
 
@@ -94,6 +95,7 @@ class ConfigHolder:
                  bit_rate_lower_bound: float = 25.0, bit_rate_higher_bound: float = 100.0,
                  launch_power_dbm: float = 0.0, frequency_start: float = 3e8 / 1565e-9,
                  frequency_slot_bandwidth: float = 12.5e9, margin: float = 0.0, channel_width: float = 12.5,
+                 nslots_channel_width: float = 0.0,
                  device: int = 0, io_device: bool = False, measure_disruptions: bool = False,
                  defragmentation: bool = False, n_defrag_services: int = 0,
                  replica_launch_power_dbm: Optional[Sequence[float]] = None,
@@ -145,6 +147,7 @@ class ConfigHolder:
         c.n_mods_consider = mtc
         c.frequency_start, c.slot_bandwidth = float(frequency_start), float(frequency_slot_bandwidth)
         c.channel_width = float(channel_width)
+        c.nslots_channel_width = float(nslots_channel_width)      # `bands`: the C band's width in Hz (quirk Q9); 0 = channel_width
         c.launch_power_w = 10 ** ((float(launch_power_dbm) - 30) / 10)  # qrmsa.pyx:288
         c.margin, c.load, c.mean_holding_time = float(margin), float(load), float(mean_service_holding_time)
         c.pair_paths = i32("pair_paths", t.pair_paths)

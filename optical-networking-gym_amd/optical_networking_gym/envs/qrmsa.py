@@ -132,8 +132,6 @@ class QRMSAEnv:
                  requests: Optional[np.ndarray] = None):
         self.gen_observation = bool(gen_observation)
         self.defragmentation, self.n_defrag_services = bool(defragmentation), int(n_defrag_services)
-        if bands and gen_observation:
-            raise NotImplementedError("bands together with gen_observation=True is not built yet")
         self.measure_disruptions = bool(measure_disruptions)
         if seed is not None and not isinstance(seed, (int, np.integer)):
             raise ValueError("Seed must be an integer.")
@@ -188,7 +186,8 @@ class QRMSAEnv:
             node_request_probabilities=node_request_probabilities, bit_rate_lower_bound=bit_rate_lower_bound,
             bit_rate_higher_bound=bit_rate_higher_bound, launch_power_dbm=launch_power_dbm,
             frequency_start=frequency_start, frequency_slot_bandwidth=frequency_slot_bandwidth, margin=margin,
-            channel_width=self._slot_width, measure_disruptions=measure_disruptions,
+            channel_width=self.channel_width, nslots_channel_width=(self._slot_width if self.current_band is not None else 0.0),
+            measure_disruptions=measure_disruptions,
             defragmentation=defragmentation, n_defrag_services=n_defrag_services)
         # service ids are kept on device so that calculate_osnr's skip-by-service-id (core/osnr.pyx:65) is exact also after a
         # counters-only reset; the id-tracking kernels need uniform attenuation (per-link attenuation: no ids, and the

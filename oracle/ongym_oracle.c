@@ -189,7 +189,9 @@ static void release_path(orc_env *e, int32_t si) {
 
 /* ---- get_number_slots (envs/qrmsa.pyx:1198-1205), bands unset: ceil(bit_rate / (SE * channel_width)) ----------- */
 int orc_number_slots(const orc_env *e, float bit_rate, int mod) {
-    double required = (double)bit_rate / ((double)e->mod_se[mod] * e->cfg.channel_width);
+    /* with `bands` the reference divides by the C band's width in Hz (quirk Q9): cfg.nslots_channel_width */
+    const double width = e->cfg.nslots_channel_width > 0 ? e->cfg.nslots_channel_width : e->cfg.channel_width;
+    double required = (double)bit_rate / ((double)e->mod_se[mod] * width);
     return (int)ceil(required);
 }
 

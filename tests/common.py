@@ -56,7 +56,7 @@ def holder_for(meta: dict, batch: int = 1, capacity: int = 1024, **over) -> Conf
               bit_rate_selection=meta["bit_rate_selection"], bit_rates=tuple(meta["bit_rates"]),
               bit_rate_lower_bound=25, bit_rate_higher_bound=100, launch_power_dbm=meta["launch_power_dbm"],
               frequency_start=meta["frequency_start"], frequency_slot_bandwidth=meta["slot_bw"],
-              margin=meta["margin"])
+              margin=meta["margin"], nslots_channel_width=meta.get("nslots_channel_width", 0.0))
     kw.update(over)
     tables = golden_tables(meta["topology"])
     if meta.get("k_paths", tables.k_paths) < tables.k_paths:     # fixtures captured with fewer candidate routes per pair

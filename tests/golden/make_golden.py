@@ -406,9 +406,13 @@ def export_kats():
 
 
 def run_observation(tag, topo_name, seed, load, S, steps, bit_rates=(10, 40, 100, 400), launch_power_dbm=0.0,
-                    margin=0.0, k=5, modulations_to_consider=6):
+                    margin=0.0, k=5, modulations_to_consider=6, bands=False):
     """gen_observation=True: observation vector (qrmsa.pyx:583-781) and action mask at every step of a first-fit run."""
     topo = load_topology(topo_name, k)
+    band_kw = {}
+    if bands:       # what graph_launch_power.py:102 passes: get_number_slots then divides by the C band's width in Hz (quirk Q9)
+        from optical_networking_gym.core.bands import BandC, BandL, BandS
+        band_kw["bands"] = [BandS(), BandC(), BandL()]
     random.Random = seeded_random(seed)
     try:
         env = QRMSAEnvWrapper(
@@ -417,7 +421,7 @@ def run_observation(tag, topo_name, seed, load, S, steps, bit_rates=(10, 40, 100
             frequency_start=3e8 / 1565e-9, frequency_slot_bandwidth=12.5e9, bit_rate_selection="discrete",
             bit_rates=bit_rates, margin=margin, file_name="", measure_disruptions=False, k_paths=k,
             modulations_to_consider=modulations_to_consider, defragmentation=False, n_defrag_services=0,
-            gen_observation=True)
+            gen_observation=True, **band_kw)
     finally:
         random.Random = _OrigRandom
     reqs = [request_tuple(env)]
@@ -427,7 +431,7 @@ def run_observation(tag, topo_name, seed, load, S, steps, bit_rates=(10, 40, 100
     maxidx_l, dec_l, acc_l = [int(env.env.max_modulation_idx)], [], []
     mask = info0["mask"]
     for i in range(steps):
-        if modulations_to_consider == 6:
+        if modulations_to_consider == 6 and not bands:
             action, _, _ = H.heuristic_shortest_available_path_first_fit_best_modulation(env)
         else:
             # the heuristics encode out-of-window formats past the codec's range (heuristics.py:36-54): act on the MASK like
@@ -455,7 +459,8 @@ def run_observation(tag, topo_name, seed, load, S, steps, bit_rates=(10, 40, 100
                    launch_power_dbm=launch_power_dbm, margin=margin, k_paths=k, episode_length=steps + 50,
                    bit_rate_selection="discrete", frequency_start=3e8 / 1565e-9, slot_bw=12.5e9,
                    mean_holding=10800.0, initial_resets=2, n_actions=int(env.env.action_space.n),
-                   modulations_to_consider=modulations_to_consider),
+                   modulations_to_consider=modulations_to_consider, bands=bool(bands),
+                   nslots_channel_width=((195.90 - 191.60) * 1e12 / 344 if bands else 0.0)),
               open(os.path.join(HERE, f"{tag}.json"), "w"), indent=1)
     print(f"{tag}: {steps} steps, obs dim {obs_l[0].shape[0]}, mask ones first/last {int(info0['mask'].sum())}/{int(info['mask'].sum())}")
 
@@ -467,6 +472,9 @@ OBS = {
     # modulations_to_consider < len(modulations): sliding window below max_modulation_idx (qrmsa.pyx:543-581, 712-717, 801-834)
     "obs_nsfnet320_mtc4": dict(topo_name="nsfnet", seed=33, load=1500, S=320, steps=140, modulations_to_consider=4),
     "obs_nsfnet160_mtc2": dict(topo_name="nsfnet", seed=34, load=900, S=160, steps=120, modulations_to_consider=2),
+    # `bands` together with gen_observation=True (graph_launch_power.py:102): every service is one slot wide (quirk Q9), the
+    # observation's frequencies still come from channel_width; driven by the reference's own mask
+    "obs_nsfnet320_bands": dict(topo_name="nsfnet", seed=35, load=3000, S=320, steps=150, bands=True),
 }
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -180,6 +180,32 @@ def test_gen_observation_through_the_wrapper():
         obs, reward, done, truncated, info = env.step(int(d["action"][i]))
 
 
+def test_bands_with_gen_observation_through_the_wrapper():
+    """The reference's own driver passes bands=[S, C, L] (graph_launch_power.py:102) and its observation runs with it: one slot
+    per service (quirk Q9), frequencies from channel_width.  QRMSAEnvWrapper(bands=..., gen_observation=True) against the
+    reference's captured run (obs_nsfnet320_bands), driven by the reference's own mask."""
+    from optical_networking_gym.core.bands import BandC, BandL, BandS
+    meta, d = load_traj("obs_nsfnet320_bands")
+    topology = get_topology(bundled_topology_path("nsfnet_chen.txt"), None, jocn_modulations(), 80, 0.2, 4.5, 5)
+    env = QRMSAEnvWrapper(topology=topology, seed=10, allow_rejection=True, load=meta["load"],
+                          episode_length=meta["episode_length"], num_spectrum_resources=320, launch_power_dbm=0.0,
+                          bandwidth=4e12, frequency_start=3e8 / 1565e-9, frequency_slot_bandwidth=12.5e9,
+                          bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), margin=0, file_name="",
+                          k_paths=5, modulations_to_consider=6, gen_observation=True, requests=traj_requests(d),
+                          bands=[BandS(), BandC(), BandL()])
+    sim = get_qrmsa_env(env)
+    assert sim.current_band.name == "C" and sim.channel_width == 12.5
+    obs, info = env.reset()
+    for i in range(40):
+        want_mask = np.unpackbits(d["mask"][i], bitorder="little")[:9601]
+        np.testing.assert_allclose(obs, d["obs"][i], rtol=2e-6, atol=2e-7)
+        np.testing.assert_array_equal(info["mask"], want_mask)
+        assert all(sim.get_number_slots(sim.current_service, m) == 1 for m in sim.modulations)
+        obs, reward, done, truncated, info = env.step(int(d["action"][i]))
+        if d["accepted"][i]:
+            assert info["chosen_path_index"] == d["decoded"][i][0] and info["chosen_slot"] == d["decoded"][i][2]
+
+
 def test_bands_quirk_and_service_csv(tmp_path):
     """bands=[S, C, L] (graph_launch_power.py:108): every service needs ONE slot (quirk Q9: SURVEY measured
     400 G -> [1,1,1,1,1,1] in the reference); file_name: per-service CSV with the reference's header (qrmsa.pyx:387-406)."""

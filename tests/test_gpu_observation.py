@@ -56,6 +56,27 @@ def test_modulations_to_consider_window_vs_reference(tag):
                 assert [rec["route"], rec["modulation"], rec["slot"]] == d["decoded"][i].tolist(), i
 
 
+def test_observation_with_bands_vs_reference():
+    """`bands` with gen_observation=True (reference driver: graph_launch_power.py:102): one slot per service (quirk Q9), the
+    observation's frequencies from channel_width; k_observe and ongym_step_actions against the reference's captured run."""
+    meta, d = load_traj("obs_nsfnet320_bands")
+    env = make_env(meta, auto_reset=False)
+    env.set_requests(traj_requests(d))
+    for _ in range(meta["initial_resets"]):
+        env.reset()
+    for i in range(meta["steps"] + 1):
+        obs, mask = env.observe()
+        want_mask = np.unpackbits(d["mask"][i], bitorder="little")[:meta["n_actions"]]
+        np.testing.assert_array_equal(mask[0], want_mask, err_msg=f"mask step {i}")
+        np.testing.assert_allclose(obs[0], d["obs"][i], rtol=2e-6, atol=2e-7, err_msg=f"obs step {i}")
+        if i < meta["steps"]:
+            rec = env.step(np.array([d["action"][i]], np.int32))[0]
+            assert not rec["retry"] and not (rec["flags"] & nat.F_QOT_ERROR)
+            assert rec["accepted"] == d["accepted"][i]
+            if rec["accepted"]:
+                assert [rec["route"], rec["modulation"], rec["slot"]] == d["decoded"][i].tolist() and rec["nslots"] == 1
+
+
 def test_modulations_to_consider_vs_oracle_mask_driven():
     """The window on evolving states: 10 replicas with different launch powers, each step observe -> lowest valid action of
     the mask (every 7th step the highest) -> step, device vs oracle in lockstep; then the fused first-fit heuristic's action

@@ -23,7 +23,8 @@ def make_env(meta, batch=1, **over):
               mean_service_holding_time=meta["mean_holding"], bit_rate_selection=meta["bit_rate_selection"],
               bit_rates=tuple(meta["bit_rates"]), bit_rate_lower_bound=25, bit_rate_higher_bound=100,
               launch_power_dbm=meta["launch_power_dbm"], frequency_start=meta["frequency_start"],
-              frequency_slot_bandwidth=meta["slot_bw"], margin=meta["margin"], capacity=1024)
+              frequency_slot_bandwidth=meta["slot_bw"], margin=meta["margin"], capacity=1024,
+              nslots_channel_width=meta.get("nslots_channel_width", 0.0))
     kw.update(over)
     return BatchedQRMSAEnv(**kw)
 

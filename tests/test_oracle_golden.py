@@ -177,6 +177,34 @@ def test_observation_and_mask_vs_reference(tag):
             assert rc == 0
 
 
+def test_observation_with_bands_vs_reference():
+    """`bands` together with gen_observation=True (the reference's own driver passes bands, graph_launch_power.py:102):
+    get_number_slots divides by the C band's width in Hz, so every candidate and every running service is ONE slot wide
+    (quirk Q9, qrmsa.pyx:417-425, 1198-1205), while the observation's frequencies keep coming from channel_width
+    (qrmsa.pyx:606-610, 678; core/osnr.pyx:259-369).  Reference run driven by its own mask, every step compared."""
+    meta, d, h, reqs = obs_setup("obs_nsfnet320_bands")
+    assert meta["bands"] and h.struct.nslots_channel_width == pytest.approx(1.25e10)
+    env = OracleEnv(h)
+    env.set_trace(reqs)
+    for _ in range(meta["initial_resets"]):
+        env.reset()
+    pl = np.ctypeslib.as_array(h.struct.path_len_norm, shape=(h.struct.n_paths,))
+    for m in range(6):
+        assert env.number_slots(400.0, m) == 1
+    for i in range(meta["steps"] + 1):
+        obs, mask = env.observe(pl, h.struct.max_bit_rate)
+        np.testing.assert_array_equal(mask, np.unpackbits(d["mask"][i], bitorder="little")[:meta["n_actions"]], err_msg=f"mask step {i}")
+        np.testing.assert_allclose(obs, d["obs"][i], rtol=2e-6, atol=2e-7, err_msg=f"obs step {i}")
+        if i < meta["steps"]:
+            a = int(d["action"][i])
+            if a != h.reject_action:
+                assert env.decode(a) == d["decoded"][i].tolist(), i
+            rc, r = env.step(a)
+            assert rc == 0 and r["accepted"] == d["accepted"][i], i
+            if r["accepted"]:
+                assert r["nslots"] == 1
+
+
 @pytest.mark.parametrize("tag", ["obs_nsfnet320_mtc4", "obs_nsfnet160_mtc2"])
 def test_modulations_to_consider_window_vs_reference(tag):
     """modulations_to_consider < len(modulations): observation() first moves max_modulation_idx

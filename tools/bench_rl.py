@@ -109,21 +109,21 @@ def main():
 
     # masked uniform sampling in two levels (blocks of 64 actions): the mask is read once as bytes; torch.multinomial on
     # mask.float() moved 5x the mask's bytes and cost as much as the observation kernel
-    nblk = (nact + 63) // 64
-    padded = torch.zeros((B, nblk * 64), dtype=torch.uint8, device=dev)
+    assert (nact - 1) % 64 == 0, "k * M * S must be a multiple of 64 for the block view (S = 320: 9600)"
+    nblk = (nact - 1) // 64
+    rows = torch.arange(B, device=dev)
 
     def sample_masked():
-        padded[:, :nact] = mask
-        blocks = padded.view(B, nblk, 64)
-        bcnt = blocks.sum(2, dtype=torch.int32)                               # valid actions per block
-        bcum = bcnt.cumsum(1, dtype=torch.int32)
-        r = (torch.rand(B, device=dev) * bcum[:, -1]).to(torch.int32)
-        r = torch.minimum(r, bcum[:, -1] - 1)                                 # r-th valid action (0-based), the reject action is always valid
-        bi = torch.searchsorted(bcum, r.unsqueeze(1), right=True).squeeze(1)  # its block
-        before = torch.where(bi > 0, bcum.gather(1, (bi - 1).clamp_(min=0).unsqueeze(1)).squeeze(1), torch.zeros_like(r))
-        blk = blocks[torch.arange(B, device=dev), bi].to(torch.int32)         # [B, 64]
-        inner = torch.searchsorted(blk.cumsum(1, dtype=torch.int32), (r - before).unsqueeze(1), right=True).squeeze(1)
-        return (bi * 64 + inner).to(torch.int32)
+        blocks = mask[:, :nact - 1].view(B, nblk, 64)                         # a view: nothing is copied
+        bcum = blocks.sum(2, dtype=torch.int32).cumsum(1, dtype=torch.int32)  # valid actions up to and including each block
+        total = bcum[:, -1] + 1                                               # + the reject action, always valid (:766)
+        r = torch.minimum((torch.rand(B, device=dev) * total).to(torch.int32), total - 1)     # the r-th valid action (0-based)
+        bi = torch.searchsorted(bcum, r.unsqueeze(1), right=True).squeeze(1)  # its block (nblk: the reject action)
+        bic = bi.clamp(max=nblk - 1)
+        before = torch.where(bi > 0, bcum.gather(1, (bi - 1).clamp(min=0).unsqueeze(1)).squeeze(1), torch.zeros_like(r))
+        inner = torch.searchsorted(blocks[rows, bic].to(torch.int32).cumsum(1, dtype=torch.int32), (r - before).unsqueeze(1),
+                                   right=True).squeeze(1)
+        return torch.where(bi >= nblk, torch.full_like(r, nact - 1), (bic * 64 + inner).to(torch.int32))
 
     def rl_step():
         env_observe()
