@@ -788,7 +788,10 @@ __device__ __forceinline__ int evaluate_action(Ctx &c, int src, int dst, double 
     ch.action = action; ch.route = -1; ch.mod = -1; ch.slot = -1; ch.n = 0; ch.flags = 0; ch.hops = 0; ch.mylink = 0;
     ch.path = -1; ch.m0 = 0; ch.g.ase = ch.g.nli = 0.0;
     if (action == P.k_paths * M * S) return 1;
-    if (action < 0 || action > P.k_paths * M * S) return 2;
+    if (action < 0) return 2;
+    // an index ABOVE the reject action is decoded like any other: encoded_decimal_to_array (qrmsa.pyx:801-834) takes the digits
+    // modulo (slots, formats, routes), so it aliases a (route, format, slot).  The heuristics produce such indices under a
+    // narrow codec (formats below the window, heuristics.py:36-54 with modulations_to_consider < len(modulations)).
     int slot = action % S; int t = action / S;
     int r = t % M; t /= M;
     int route = t % P.k_paths;

@@ -1,12 +1,13 @@
-// ongym_fast.hpp — the lean fused first-fit kernel (k_fast): same path and same results as k_run<…, FIRST_FIT>, built around
-// ISSUE-SLOT economy.  tools/ubench/issue_rates.hip measured on MI355X (cycles per wave-instruction per SIMD, >= 2 waves):
-// 32-bit VALU 2.5, fp64 / 64-bit shift / DPP mov / v_readlane / v_alignbit 4.2, SALU 4.3, ds_read_b32 ~9.  The round-1
-// kernel spent 726 VALU + 625 SALU per request; at 5 waves/SIMD both pipes were ~2/3 busy, i.e. it was issue-bound on
-// both.  What this kernel does differently (reference semantics unchanged: envs/qrmsa.pyx:838-1122,
-// heuristics/heuristics.py:923-966, core/osnr.pyx:21-142):
+// ongym_fast.hpp — the lean fused policy + step kernels (k_fast<M64, REC, ENT, WAVES, TRACE, POL>): same path and same results
+// as the generic k_run, built around ISSUE-SLOT economy.  tools/ubench/issue_rates.hip measured on MI355X (cycles per
+// wave-instruction per SIMD, >= 2 waves): 32-bit VALU 2.5, fp64 / 64-bit shift / DPP mov / v_readlane / v_alignbit 4.2,
+// SALU 4.3, ds_read_b32 ~9.  The round-1 kernel spent 726 VALU + 625 SALU per request; at 5 waves/SIMD both pipes were
+// ~2/3 busy, i.e. it was issue-bound on both.  What these kernels do differently (reference semantics unchanged:
+// envs/qrmsa.pyx:838-1122, core/osnr.pyx:21-142, and per policy heuristics/heuristics.py:923-966 first fit, :547-627 load
+// balancing, :272-328 highest SNR, :330-414 lowest fragmentation - the four heuristics of graph_load.py:116-125):
 //   * requests are drawn 64 at a time (lane i = request index base+i of the same counter-based stream,
-//     include/ongym_traffic.h) and kept in three VGPRs; a step pops one with v_readlane.  The float32 clock chain stays
-//     serial (one v_add_f32 per request).
+//     include/ongym_traffic.h) or read 64 at a time from a replayed trace, and kept in three VGPRs; a step pops one with
+//     v_readlane.  The float32 clock chain stays serial (one v_add_f32 per request).
 //   * no DevEnv in LDS and no lane-0 read-modify-write chains: wave-uniform counters are plain (scalar) variables, the
 //     per-modulation / per-bit-rate histograms one lane-distributed VGPR (v_cmp + v_addc); everything is folded into
 //     DevEnv in memory at the end of the launch and around the (rare) terminal step.
@@ -21,12 +22,17 @@
 //     fp64 FMAs per interferer; the acceptance test runs lane-parallel against per-lane limits (no readlane of doubles).
 //   * records are 8 bytes in LDS (link mask | centre, modulation, slots-1, path) + the float32 release time; unused
 //     entries are neutral (mask 0, release +inf), so no scan needs a bounds test.
+//   * policies that look at every route fetch the routes' ids and records together (lane k = k-th route) and examine the
+//     routes in the order that makes the FIRST route that serves the request the answer (ascending load / score);
+//     policies that evaluate many starts of a (route, format) put the candidates on the lanes (eval_cands).
 // The state in HBM is the generic kernels' (same arrays, same record codec), converted on load / store: every other entry
 // point keeps working on the same environment, and a launch may be split anywhere.
 //
-// Eligibility (checked on the host, fast_eligible): first-fit policy-step mode, device request generator, discrete bit
-// rates (<= 8, integer-valued), uniform attenuation, ase_shortcut, no defragmentation / disruptions, n_links <= 52,
-// n_nodes <= 64, max_hops <= 16, every slot count of the traffic table <= min(512, tab_nmax), 2S+1 < 2048.
+// Eligibility (checked on the host in build(), ongym_hip.hip; lean_policy() there decides per launch): policy-step mode,
+// device request generator or a host trace whose bit rates all come from the configured table, discrete bit rates (<= 8,
+// integer-valued), uniform attenuation, ase_shortcut, no defragmentation / disruptions / id tracking,
+// modulations_to_consider == n_mods, n_links <= 52, n_nodes <= 64, every slot count of the traffic table <= min(512,
+// tab_nmax), 2S+1 < 2048, and the policy's LDS block within 160 KiB.
 #pragma once
 #include "ongym_device.hpp"
 

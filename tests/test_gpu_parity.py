@@ -1211,3 +1211,44 @@ def test_caller_stream_equals_own_stream():
     got = recs.cpu().numpy().view(nat.STEP_DTYPE).reshape(steps, B)
     for f in nat.STEP_DTYPE.names:
         assert np.array_equal(got[f], out[0][f]), f
+
+
+def test_action_above_the_reject_index_wraps_like_the_reference():
+    """encoded_decimal_to_array (qrmsa.pyx:801-834) decodes by modulo: an action index above the reject action aliases a
+    (route, format, slot) - the heuristics produce such indices under a narrow codec (route K-1 with a format more than
+    modulations_to_consider - 1 below max_modulation_idx, heuristics.py:36-54).  Device step vs the oracle's step in lockstep
+    on nobel-eu at low launch power (long routes force low formats), both for hand-made indices and for the fused first fit
+    under a narrow codec; at least one index above the reject action must occur."""
+    B, Mc, S, steps = 8, 2, 160, 220
+    tb = golden_tables("nobel-eu")
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=S, capacity=512, load=250, bit_rate_selection="discrete",
+              bit_rates=(10, 40, 100, 400), auto_reset=True, modulations_to_consider=Mc, launch_power_dbm=-6.0)
+    holder = nat.ConfigHolder(tb, batch=B, **kw)
+    env = BatchedQRMSAEnv(tables=tb, batch_size=B, **kw)
+    env.seed(5); env.reset()
+    oracles = []
+    for r in range(B):
+        o = OracleEnv(holder, replica=r); o.seed(5); o.reset()
+        oracles.append(o)
+    reject = env.reject_action
+    above = 0
+    for t in range(steps):
+        acts, _ = env.policy_actions()
+        for r, o in enumerate(oracles):
+            assert acts[r] == o.policy_first_fit()[0], (t, r)
+        if t % 5 == 4:
+            acts = acts.copy()
+            acts[t % B] = reject + 1 + (7 * t) % (3 * S)      # a hand-made index above the reject action
+        above += int((acts > reject).sum())
+        rec = env.step(acts)
+        for r, o in enumerate(oracles):
+            rc, w = o.step(int(acts[r]))
+            if rc != 0:           # the reference raises on a QoT-infeasible action: flagged, nothing applied, next try is a reject
+                assert rec[r]["flags"] & nat.F_QOT_ERROR, (t, r)
+                rec_r = env.step(np.where(np.arange(B) == r, reject, -1).astype(np.int32))      # -1: occupied-slots penalty elsewhere
+                rc2, w2 = o.step(reject)
+                assert rc2 == 0
+                continue
+            for f in ("accepted", "route", "modulation", "slot", "nslots", "active", "retry"):
+                assert rec[r][f] == w[f], (t, r, f, int(acts[r]))
+    assert above >= steps // 5
