@@ -95,6 +95,9 @@ struct Params {
     int tab_nmax, tab_stride;
     // lean first-fit kernel (ongym_fast.hpp); NULL when the configuration is not eligible
     const void *path_rec;           // PathRec [P]
+    const uint64_t *path_hash_keys; // lean M64 record codec: link mask (bits 0..40) -> path id, open addressing, 2^path_hash_bits slots
+    const int32_t *path_hash_vals;
+    int path_hash_bits, pad_hash;
     const double *pair_tab2k;       // the pair table with a row pitch of 2048 entries: [tab_nmax][2048][2]
     const double *pair_tabp;        // the same rows split by the parity of the distance: [tab_nmax][2][1024][2], entry (d & 1, d >> 1).
                                     // Candidate centres of one format are two half slots apart: consecutive candidates then

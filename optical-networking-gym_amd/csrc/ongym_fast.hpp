@@ -74,7 +74,7 @@ __host__ __device__ inline size_t fast_lds_bytes(int n_links, int row_words, int
                                                  int policy = ONGYM_POLICY_FIRST_FIT) {
     size_t b = ((size_t)n_links * row_words * 8 + 15) & ~(size_t)15;   // occ  u32 [E][2W]
     b += (size_t)(n_links + 1) * 16 + 64;                               // lw (w1,w2) [E + a zero entry] | phi [8]
-    b += (size_t)(capacity + 1) * 8 + (m64 ? (size_t)(capacity + 1) * 4 : 0);   // rec {a,b} | (a2), + one neutral entry
+    b += (size_t)(capacity + 1) * 8;                                    // rec {a,b}, + one neutral entry
     b += (size_t)capacity * (4 + 2);                                    // rr | list
     b += 48;                                                            // cold wave-uniform state (5 doubles)
     b = (b + 15) & ~(size_t)15;
@@ -156,10 +156,20 @@ __device__ __forceinline__ uint32_t word_mask32(int w, int lo, int hi) {     // 
     return (b - a == 32) ? ~0u : (((1u << (b - a)) - 1u) << a);
 }
 
-// record word b: centre 2*slot+n (11 bits) | modulation << 11 | (n-1) << 14 (9 bits) | path << 23 (9 bits)
+// record word b:   centre 2*slot+n (11 bits) | modulation << 11 | (n-1) << 14 (9 bits) | path << 23 (9 bits)
+// with M64 (33..41 links): centre (11) | modulation << 11 | (n-1) << 14 (9 bits) | link-mask bits 32..40 << 23.
+// The path id is not in the M64 record: a route is identified by its link set (the two directions of a node pair share their
+// Path objects, topology.pyx:310-355, i.e. their ids), and the store at the end of a launch looks the id up in a hash table
+// built at create (Params.path_hash_*; a table with two ids for one link set keeps the generic kernel).
+constexpr uint32_t kM64HiBits = 9;                   // links 32..40 of the mask live in the record word
 __device__ __forceinline__ uint32_t fast_pack_b(int slot, int n, int mod, int path) {
     return (uint32_t)(2 * slot + n) | ((uint32_t)mod << 11) | ((uint32_t)(n - 1) << 14) | ((uint32_t)(path & 0x1FF) << 23);
 }
+__device__ __forceinline__ uint32_t fast_pack_b64(int slot, int n, int mod, uint32_t mask_hi) {
+    return (uint32_t)(2 * slot + n) | ((uint32_t)mod << 11) | ((uint32_t)(n - 1) << 14) | (mask_hi << 23);
+}
+template <bool M64> __device__ __forceinline__ uint32_t rec_nm1(uint32_t y) { return (y >> 14) & 0x1FFu; }   // slots - 1
+__host__ __device__ inline uint32_t path_hash_slot(uint64_t key, int bits) { return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - bits)); }
 
 
 // 64 requests at once: lane i evaluates ongym_draw_request (include/ongym_traffic.h) for request index base + i, except the
@@ -230,7 +240,6 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
     double *const lw = reinterpret_cast<double *>(smem + o); o += (size_t)(E + 1) * 16;      // lw[2E], lw[2E+1] = 0
     double *const phi = reinterpret_cast<double *>(smem + o); o += 64;
     uint2 *const rec = reinterpret_cast<uint2 *>(smem + o); o += (size_t)(C + 1) * 8;           // rec[C]: neutral entry
-    uint32_t *const a2 = reinterpret_cast<uint32_t *>(smem + o); if (M64) o += (size_t)(C + 1) * 4;
     float *const rr = reinterpret_cast<float *>(smem + o); o += (size_t)C * 4;
     uint16_t *const list = reinterpret_cast<uint16_t *>(smem + o); o += (size_t)C * 2;
     // wave-uniform state that is touched once in ~60 steps or less lives in LDS, not in registers:
@@ -243,7 +252,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
     uint2 *const st_ck = reinterpret_cast<uint2 *>(smem + o_x + (((size_t)(S + 1) * 2 + 15) & ~(size_t)15));
     double2 *const st_w = reinterpret_cast<double2 *>(st_ck + 64);
     double *const plt = reinterpret_cast<double *>(st_w + 64);
-    const uint32_t occ_base = lds_addr(occ), rec_base = lds_addr(rec), rr_base = lds_addr(rr), a2_base = lds_addr(a2);
+    const uint32_t occ_base = lds_addr(occ), rec_base = lds_addr(rec), rr_base = lds_addr(rr);
     // A zero the compiler cannot see through.  Wave-uniform integer arithmetic that only feeds LDS addresses and data is cheaper
     // on the vector pipe (2.5 cycles per instruction, ~60 % busy) than on the scalar pipe (4.3 cycles, ~70 % busy, and its
     // results would need v_mov to become DS operands anyway): adding `vz` to one operand keeps such a chain in VGPRs.
@@ -275,13 +284,12 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                     slot = rec_slot<false>(a, b); n = rec_n<false>(a, b); mod = rec_mod<false>(a, b); path = rec_path<false>(a, b);
                     const uint64_t m0 = G(P.path_mask)[2 * path];
                     ab.x = (uint32_t)m0;
-                    hi = (uint32_t)(m0 >> 32) | ((uint32_t)(path >> 9) << 20);
+                    hi = (uint32_t)(m0 >> 32);
                 }
-                ab.y = fast_pack_b(slot, n, mod, path);
+                ab.y = M64 ? fast_pack_b64(slot, n, mod, hi) : fast_pack_b(slot, n, mod, path);
             }
             rec[i] = ab;
             if (i < C) rr[i] = r;
-            if (M64) a2[i] = hi;
         }
     }
 
@@ -574,7 +582,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             return r;
         };
         auto mask_of = [&](const PathRec &pr) -> uint64_t {
-            return M64 ? ((uint64_t)pr.mask_lo | ((uint64_t)(pr.mask_hi & 0xFFFFFu) << 32)) : (uint64_t)pr.mask_lo;
+            return M64 ? ((uint64_t)pr.mask_lo | ((uint64_t)(pr.mask_hi & 0x1FFu) << 32)) : (uint64_t)pr.mask_lo;
         };
         // LOAD_BALANCING keeps the route of lowest load among those that serve the request, the first of them on ties (a route
         // only replaces the solution when its load is strictly lower, :571-575, :612-616); LOWEST_FRAGMENTATION the same with the
@@ -656,13 +664,13 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             auto intf_of = [&](int idx, uint32_t mask_lo, uint32_t mask_hi, uint32_t &c2k, uint32_t &key4, double &w1o, double &pw2o) -> int {
                 const uint2 ab = rec[idx];
                 c2k = ab.y & 0x7FFu;
-                key4 = ((ab.y >> 14) & 0x1FFu) << 15;           // (n-1) * kTabPitch entries * 16 bytes
+                key4 = rec_nm1<M64>(ab.y) << 15;                // (n-1) * kTabPitch entries * 16 bytes
                 uint32_t mm = ab.x & mask_lo;
                 double w1 = 0.0, w2 = 0.0;
                 int terms = __popc(mm);
                 while (mm) { const int l = __ffs(mm) - 1; mm &= mm - 1; w1 += lw[2 * l]; w2 += lw[2 * l + 1]; }
                 if (M64) {
-                    uint32_t mh = a2[idx] & mask_hi & 0xFFFFFu;
+                    uint32_t mh = (ab.y >> 23) & mask_hi;
                     terms += __popc(mh);
                     while (mh) { const int l = 32 + __ffs(mh) - 1; mh &= mh - 1; w1 += lw[2 * l]; w2 += lw[2 * l + 1]; }
                 }
@@ -677,7 +685,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                     const int i0 = base + lane, i1 = i0 + kWave;
                     const int i1c = min(i1, C);          // beyond the table: the neutral entry
                     bool ov0 = (rec[i0].x & mask_lo) != 0, ov1 = (rec[i1c].x & mask_lo) != 0;    // unused entries: mask 0
-                    if (M64) { ov0 |= (a2[i0] & mask_hi & 0xFFFFFu) != 0; ov1 |= (a2[i1c] & mask_hi & 0xFFFFFu) != 0; }
+                    if (M64) { ov0 |= ((rec[i0].y >> 23) & mask_hi) != 0; ov1 |= ((rec[i1c].y >> 23) & mask_hi) != 0; }
                     const uint64_t bal0 = __ballot(ov0), bal1 = __ballot(ov1);
                     const int n0 = __popcll((unsigned long long)bal0);
                     const int p0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal0, 0));
@@ -928,9 +936,9 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             int end = ch_slot + ch_n; if (end < S) end += 1;
             mark(ch_mask, ch_slot, end, false);
             const float rel = v_at + cur_ht;                  // float + float (:1329); compared as float32 (:1114-1115)
-            const uint32_t ra = (uint32_t)ch_mask, rb = fast_pack_b(ch_slot, ch_n, ch_m, ch_path);
+            const uint32_t ra = (uint32_t)ch_mask;
+            const uint32_t rb = M64 ? fast_pack_b64(ch_slot, ch_n, ch_m, (uint32_t)(ch_mask >> 32)) : fast_pack_b(ch_slot, ch_n, ch_m, ch_path);
             lds_write_lane0(rec_base + (uint32_t)active * 8u, (uint64_t)ra | ((uint64_t)rb << 32), rr_base + (uint32_t)active * 4u, __float_as_uint(rel));
-            if (M64) lds_write_lane0_b32(a2_base + (uint32_t)active * 4u, (uint32_t)(ch_mask >> 32) | ((uint32_t)(ch_path >> 9) << 20));
             active++;
             d_acc++;
             cnt += (lane == 8 + ch_m || lane == 24 + cur_bi) ? 1 : 0;
@@ -957,7 +965,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                     const int path = uniform_i32(KC(P.pair_paths)[(cur_src * N + cur_dst) * K + k]);
                     if (path < 0) break;
                     const PathRec pr = load_path_rec(path_recs, path);
-                    const uint32_t x = path_and(M64 ? ((uint64_t)pr.mask_lo | ((uint64_t)(pr.mask_hi & 0xFFFFFu) << 32)) : (uint64_t)pr.mask_lo);
+                    const uint32_t x = path_and(M64 ? ((uint64_t)pr.mask_lo | ((uint64_t)(pr.mask_hi & 0x1FFu) << 32)) : (uint64_t)pr.mask_lo);
                     int r1 = 1;
                     if (first_set32(run_and32(x, r1, n_small + 1)) >= 0) bosnr = 1;
                 }
@@ -978,7 +986,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                     const int path = uniform_i32(KC(P.pair_paths)[(cur_src * N + cur_dst) * K + k]);
                     if (path < 0) break;
                     const PathRec pr = load_path_rec(path_recs, path);
-                    const uint32_t x = path_and(M64 ? ((uint64_t)pr.mask_lo | ((uint64_t)(pr.mask_hi & 0xFFFFFu) << 32)) : (uint64_t)pr.mask_lo);
+                    const uint32_t x = path_and(M64 ? ((uint64_t)pr.mask_lo | ((uint64_t)(pr.mask_hi & 0x1FFu) << 32)) : (uint64_t)pr.mask_lo);
                     int r1 = 1;
                     const bool any = first_set32(run_and32(x, r1, n_small + 1)) >= 0;
                     if (any) { bosnr = 1; bres = 0; }
@@ -1054,13 +1062,13 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                 bal &= ~(1ull << ln);
                 const int idx = ch * kWave + ln;
                 const uint2 ab = rec[idx + vz];                             // same address in every lane: broadcast read
-                const uint32_t nk = ((ab.y >> 14) & 0x1FFu) + 1u, sk = ((ab.y & 0x7FFu) - nk) >> 1;
+                const uint32_t nk = rec_nm1<M64>(ab.y) + 1u, sk = ((ab.y & 0x7FFu) - nk) >> 1;
                 const uint32_t hi = min(sk + nk + 1u, (uint32_t)S);         // frees n+1 slots, clamped at S (quirk Q7)
                 if (__builtin_amdgcn_readfirstlane(nk) <= 32u)
-                    mark_v(ab.x, M64 ? (a2[idx + vz] & 0xFFFFFu) : 0u, sk, hi - sk, true);
+                    mark_v(ab.x, M64 ? (ab.y >> 23) : 0u, sk, hi - sk, true);
                 else {
                     uint64_t mask = __builtin_amdgcn_readfirstlane(ab.x);
-                    if (M64) mask |= (uint64_t)(__builtin_amdgcn_readfirstlane(a2[idx]) & 0xFFFFFu) << 32;
+                    if (M64) mask |= (uint64_t)(__builtin_amdgcn_readfirstlane(ab.y) >> 23) << 32;
                     mark(mask, (int)__builtin_amdgcn_readfirstlane(sk), (int)__builtin_amdgcn_readfirstlane(hi), true);
                 }
                 const int last = active - 1;
@@ -1069,10 +1077,8 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                 const float lr = rr[last];
                 if (idx != last) {
                     lds_write_lane0(rec_base + (uint32_t)idx * 8u, (uint64_t)lab.x | ((uint64_t)lab.y << 32), rr_base + (uint32_t)idx * 4u, __float_as_uint(lr));
-                    if (M64) lds_write_lane0_b32(a2_base + (uint32_t)idx * 4u, a2[last]);
                 }
                 lds_write_lane0(rec_base + (uint32_t)last * 8u, 0ull, rr_base + (uint32_t)last * 4u, 0x7F800000u);
-                if (M64) lds_write_lane0_b32(a2_base + (uint32_t)last * 4u, 0u);
                 active = last;
                 wave_sync();
                 FSTAMP(9);
@@ -1097,7 +1103,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         if (terminated && P.auto_reset) {
             // reset (:427-504): empty network, episode counters to zero, draw request #0 of the next episode
             for (int i = lane; i < E * RW; i += kWave) occ[i] = word_mask32(i % RW, 0, S);
-            for (int i = lane; i < active; i += kWave) { rec[i] = make_uint2(0u, 0u); rr[i] = INFINITY; if (M64) a2[i] = 0; }
+            for (int i = lane; i < active; i += kWave) { rec[i] = make_uint2(0u, 0u); rr[i] = INFINITY; }
             active = 0;
             epp = 0; erej = 0; cnt = 0;
             if (lane < 5) cold[lane] = 0.0;
@@ -1117,9 +1123,17 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         const size_t off = (size_t)replica * C;
         for (int i = lane; i < active; i += kWave) {
             const uint2 ab = rec[i];
-            const int n = (int)((ab.y >> 14) & 0x1FFu) + 1, slot = ((int)(ab.y & 0x7FFu) - n) >> 1, mod = (int)((ab.y >> 11) & 7u);
+            const int n = (int)rec_nm1<M64>(ab.y) + 1, slot = ((int)(ab.y & 0x7FFu) - n) >> 1, mod = (int)((ab.y >> 11) & 7u);
             int path = (int)(ab.y >> 23);
-            if (M64) path |= (int)(a2[i] >> 20) << 9;
+            if (M64) {      // link set -> path id: open addressing; every route's link set is in the table (built at create), and the
+                            // probe is bounded by the table size all the same
+                const uint64_t key = (uint64_t)ab.x | ((uint64_t)(ab.y >> 23) << 32);
+                const uint32_t hm = (1u << P.path_hash_bits) - 1u;
+                uint32_t h = path_hash_slot(key, P.path_hash_bits);
+                path = 0;
+                for (uint32_t tries = 0; tries <= hm; tries++, h = (h + 1u) & hm)
+                    if (G(P.path_hash_keys)[h] == key) { path = G(P.path_hash_vals)[h]; break; }
+            }
             uint32_t ga, gb;
             if (P.rec32) rec_pack<true>(path, ab.x, slot, n, mod, ga, gb);
             else rec_pack<false>(path, 0, slot, n, mod, ga, gb);

@@ -595,11 +595,33 @@ static int build(ongym_env *env, const ongym_config *c) {
         const bool m64 = !P.rec32;
         const size_t flds = fast_lds_bytes(E, P.row_words, c->capacity, m64);
         if (flds > 160 * 1024) ok = false;
+        P.path_hash_keys = nullptr; P.path_hash_vals = nullptr; P.path_hash_bits = 0; P.pad_hash = 0;
+        if (ok && m64) {
+            // the M64 record keeps the link set (<= 41 bits) instead of the path id: it must identify the route
+            if (E > 32 + (int)kM64HiBits) ok = false;
+            int bits = 4;
+            while ((1 << bits) < 4 * NP) bits++;
+            std::vector<uint64_t> keys((size_t)1 << bits, ~0ull);
+            std::vector<int32_t> vals((size_t)1 << bits, -1);
+            for (int p = 0; p < NP && ok; p++) {
+                const uint64_t key = mask[2 * p];
+                uint32_t h = path_hash_slot(key, bits);
+                while (keys[h] != ~0ull && keys[h] != key) h = (h + 1u) & ((1u << bits) - 1u);
+                if (keys[h] == key) ok = false;          // two path ids with the same link set: keep the generic kernel
+                keys[h] = key; vals[h] = p;
+            }
+            if (ok) {
+                if ((rc = upload(env, keys.data(), keys.size(), &P.path_hash_keys))) return rc;
+                if ((rc = upload(env, vals.data(), vals.size(), &P.path_hash_vals))) return rc;
+                P.path_hash_bits = bits;
+            }
+        }
         if (ok) {
             std::vector<PathRec> recs((size_t)NP);
             for (int p = 0; p < NP; p++) {
                 PathRec &r = recs[(size_t)p];
-                r.hops = (uint32_t)c->path_hops[p]; r.mask_lo = (uint32_t)mask[2 * p]; r.mask_hi = (uint32_t)(mask[2 * p] >> 32);
+                r.hops = (uint32_t)c->path_hops[p]; r.mask_lo = (uint32_t)mask[2 * p];
+                r.mask_hi = (uint32_t)(mask[2 * p] >> 32);
                 r.id = (uint32_t)p; r.ase = path_ase[(size_t)p]; r.w1 = path_w1[(size_t)p];
             }
             const PathRec *d_recs = nullptr;
