@@ -1252,3 +1252,27 @@ def test_action_above_the_reject_index_wraps_like_the_reference():
             for f in ("accepted", "route", "modulation", "slot", "nslots", "active", "retry"):
                 assert rec[r][f] == w[f], (t, r, f, int(acts[r]))
     assert above >= steps // 5
+
+
+def test_m64_interferers_beyond_the_register_cache_vs_oracle():
+    """nobel-eu (41 links: the M64 lean kernel, whose interferer list only holds the 256 entries of the register cache) under
+    a load that puts far more than 256 interferers on a route: the ones beyond the cache are found by the second scan of the
+    records (eval_one, csrc/ongym_fast.hpp).  Records and grids against the oracle, first fit and load balancing."""
+    tb = golden_tables("nobel-eu")
+    B, steps = 6, 1400
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=768, capacity=1536, load=1500, bit_rate_selection="discrete",
+              bit_rates=(10, 40, 100), auto_reset=True, episode_length=2000)
+    holder = nat.ConfigHolder(tb, batch=B, **kw)
+    for pid in (nat.POLICY_FIRST_FIT, nat.POLICY_LOAD_BALANCING):
+        env = BatchedQRMSAEnv(tables=tb, batch_size=B, **kw)
+        env.seed(41); env.reset()
+        assert env.occupancy(pid)["lean_kernel"]
+        got = env.step_policy(steps, policy=pid)
+        st = env.stats()
+        assert st["active"].min() > 800                      # ~45 % of them share a link with a 5-hop route
+        assert (st["total_interferer_terms"] / np.maximum(st["total_gn_evals"], 1)).max() > 200
+        for r in range(B):
+            o = OracleEnv(holder, replica=r)
+            o.seed(41); o.reset()
+            assert_records_equal(got[:, r], o.run_policy(pid, steps), f"policy {pid} replica {r}")
+            np.testing.assert_array_equal(env.grid(r), o.grid())
