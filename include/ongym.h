@@ -270,6 +270,14 @@ int ongym_policy_actions(ongym_env *env, int32_t policy, int32_t *actions, uint8
  * attenuation the interferer field is evaluated term by term (no pair table): same results, about ten times slower. */
 int ongym_observe(ongym_env *env, float *obs, uint8_t *mask);
 
+/* One uniformly random VALID action per replica from an action mask [batch][k_paths*Mc*n_slots + 1] (as ongym_observe
+ * writes it): what gymnasium's `action_space.sample(mask=info["mask"])` does on the reference's Discrete action space
+ * (qrmsa.pyx:319-321; wrappers/qrmsa_gym.py:74-75 hands the mask out) - the masked random policy that exercises the
+ * observation path.  Deterministic in (seed, draw_index, global replica index); the stream is this library's counter-based
+ * generator (include/ongym_traffic.h), not NumPy's.  The reject action is always valid, so a choice always exists.
+ * mask / actions: host buffers, or device buffers with cfg.io_device (then nothing synchronises). */
+int ongym_sample_actions(ongym_env *env, const uint8_t *mask, uint64_t seed, uint64_t draw_index, int32_t *actions);
+
 /* Plugin-API queries on one replica (host buffers always): */
 /* QRMSAEnv.get_available_slots(path) (qrmsa.pyx:1482-1512): out[n_slots], 1 = free on every link of the path */
 int ongym_query_available(ongym_env *env, int32_t replica, int32_t path_id, int32_t *out);

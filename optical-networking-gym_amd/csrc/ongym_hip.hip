@@ -197,6 +197,56 @@ __global__ void k_reset_counters(Params P, const uint8_t *mask) {
     for (int i = 0; i < s.active; i++) rr[i] = copysignf(INFINITY, rr[i]);
 }
 
+// ongym_sample_actions: one wave per replica.  The mask bytes are 0/1: the row is read as aligned dwords (lane-contiguous,
+// popcount of w & 0x01010101) plus at most six head / tail bytes; any fixed order of the entries gives a uniform choice, so
+// the order is "by lane, then by the lane's strided dwords": pass 1 counts per lane, a wave scan picks the lane that holds the
+// r-th valid entry, pass 2 (the same loads, L2-resident) finds it.
+__global__ __launch_bounds__(64) void k_sample_mask(const uint8_t *__restrict__ mask, long long nact, uint64_t seed, uint64_t replica_base,
+                                                    uint64_t draw, int32_t *__restrict__ actions) {
+    const int lane = threadIdx.x;
+    const long long replica = blockIdx.x;
+    const uint8_t *row = mask + replica * nact;
+    const uintptr_t a0 = ((uintptr_t)row + 3) & ~(uintptr_t)3, a1 = ((uintptr_t)(row + nact)) & ~(uintptr_t)3;
+    const long long head = (long long)(a0 - (uintptr_t)row);                      // bytes before the aligned middle (0..3)
+    const long long ndw = a1 > a0 ? (long long)((a1 - a0) >> 2) : 0;               // aligned dwords
+    const long long tail0 = head + 4 * ndw;                                        // first tail byte (element index)
+    const uint32_t *mid = reinterpret_cast<const uint32_t *>(a0);
+    // lanes 0..2: one head byte each, lanes 3..5: one tail byte each
+    long long extra = -1;
+    if (lane < 3 && lane < head) extra = lane;
+    if (lane >= 3 && lane < 6 && tail0 + (lane - 3) < nact) extra = tail0 + (lane - 3);
+    int cnt = (extra >= 0 && row[extra]) ? 1 : 0;
+    for (long long j = lane; j < ndw; j += 64) cnt += __popc(mid[j] & 0x01010101u);
+    // inclusive scan of the per-lane counts
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(incl, d); if (lane >= d) incl += u; }
+    const int total = __shfl(incl, 63);
+    int choice = (int)(nact - 1);                                                  // the reject action (always valid)
+    if (total > 0) {
+        const double u = ongym_uniform(ongym_stream_key(seed ^ 0x9E3779B97F4A7C15ull, replica_base + (uint64_t)replica), draw);
+        int r = (int)(u * (double)total);
+        r = r >= total ? total - 1 : r;
+        const uint64_t at = __ballot(incl > r);                                    // first lane whose inclusive count exceeds r
+        const int owner = __builtin_ctzll(at);
+        if (lane == owner) {
+            int k = r - (incl - cnt);                                              // k-th valid entry of this lane (0-based)
+            long long found = -1;
+            if (extra >= 0 && row[extra]) { if (k == 0) found = extra; k--; }
+            for (long long j = lane; j < ndw && found < 0; j += 64) {
+                uint32_t w = mid[j] & 0x01010101u;
+                const int c = __popc(w);
+                if (k < c) {
+                    for (int b = 0; b < 4; b++)
+                        if ((w >> (8 * b)) & 1u) { if (k == 0) { found = head + 4 * j + b; break; } k--; }
+                } else k -= c;
+            }
+            if (found >= 0) choice = (int)found;
+            actions[replica] = choice;
+        }
+    } else if (lane == 0) actions[replica] = choice;
+}
+
 __global__ void k_rewind(Params P) {   // new trace: cursor back to 0
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= P.batch) return;
@@ -855,6 +905,7 @@ int ongym_seed_base(ongym_env *env, uint64_t seed, uint64_t replica_base) {
     HIP_TRY(env, hipSetDevice(env->cfg.device));
     env->P.req_mode = kReqRng;
     env->has_source = true;
+    env->replica_base = replica_base;
     { int rc = push_params(env); if (rc) return rc; }
     int threads = 256, blocks = (env->P.batch + threads - 1) / threads;
     hipLaunchKernelGGL(k_seed, dim3(blocks), dim3(threads), 0, env->stream, env->P, seed, replica_base);
@@ -1132,6 +1183,31 @@ int ongym_observe(ongym_env *env, float *obs, uint8_t *mask) {
     if (!env->cfg.io_device) {
         HIP_TRY(env, hipMemcpyAsync(obs, d_obs, B * obs_dim * sizeof(float), hipMemcpyDeviceToHost, env->stream));
         HIP_TRY(env, hipMemcpyAsync(mask, d_mask, B * nact, hipMemcpyDeviceToHost, env->stream));
+        HIP_TRY(env, hipStreamSynchronize(env->stream));
+    }
+    return ONGYM_OK;
+}
+
+int ongym_sample_actions(ongym_env *env, const uint8_t *mask, uint64_t seed, uint64_t draw_index, int32_t *actions) {
+    if (!env || !mask || !actions) return env ? fail_arg(env, "null mask/actions") : ONGYM_E_ARG;
+    HIP_TRY(env, hipSetDevice(env->cfg.device));
+    const Params &P = env->P;
+    const size_t nact = (size_t)P.k_paths * P.n_mods_consider * P.n_slots + 1, B = (size_t)P.batch;
+    const uint8_t *d_mask = mask;
+    int32_t *d_act = actions;
+    if (!env->cfg.io_device) {
+        if (!env->d_obsmask) {
+            HIP_TRY(env, hipMalloc(reinterpret_cast<void **>(&env->d_obsmask), B * nact));
+            env->allocs.push_back(env->d_obsmask);
+        }
+        HIP_TRY(env, hipMemcpyAsync(env->d_obsmask, mask, B * nact, hipMemcpyHostToDevice, env->stream));
+        d_mask = env->d_obsmask; d_act = env->d_act_out;
+    }
+    hipLaunchKernelGGL(k_sample_mask, dim3(P.batch), dim3(64), 0, env->stream, d_mask, (long long)nact, seed, env->replica_base,
+                       draw_index, d_act);
+    HIP_TRY(env, hipGetLastError());
+    if (!env->cfg.io_device) {
+        HIP_TRY(env, hipMemcpyAsync(actions, d_act, B * 4, hipMemcpyDeviceToHost, env->stream));
         HIP_TRY(env, hipStreamSynchronize(env->stream));
     }
     return ONGYM_OK;

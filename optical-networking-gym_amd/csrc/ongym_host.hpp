@@ -27,6 +27,7 @@ struct ongym_env {
     float *d_obs = nullptr; uint8_t *d_obsmask = nullptr;   // lazily allocated staging for ongym_observe with host buffers
     int32_t *d_scratch_i = nullptr; size_t scratch_i_bytes = 0; double *d_scratch_d = nullptr;
     bool has_source = false;
+    uint64_t replica_base = 0;      // global index of this environment's first replica (ongym_seed_base)
     std::vector<double> cfg_bit_rates;     // host copy of the discrete bit rates
     bool fast_ok = false;           // the configuration is eligible for k_fast (see fast_eligible)
     bool fast_m64 = false;

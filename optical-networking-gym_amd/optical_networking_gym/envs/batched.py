@@ -145,6 +145,17 @@ class BatchedQRMSAEnv:
                     "ongym_policy_actions")
         return actions, flags
 
+    def sample_actions(self, mask: np.ndarray, seed: int, draw_index: int) -> np.ndarray:
+        """One uniformly random valid action per replica from an action mask [batch, n_actions] (gymnasium's
+        `action_space.sample(mask=...)` on the reference's Discrete space), drawn on device (ongym_sample_actions)."""
+        mask = np.ascontiguousarray(mask, np.uint8)
+        if mask.shape != (self.batch_size, self.num_actions):
+            raise ValueError("mask must be [batch, n_actions]")
+        actions = np.zeros(self.batch_size, np.int32)
+        self._check(self.lib.ongym_sample_actions(self._h, mask.ctypes.data, C.c_uint64(seed), C.c_uint64(draw_index),
+                                                  actions.ctypes.data), "ongym_sample_actions")
+        return actions
+
     def observe(self):
         """observation() + action mask of every replica's current request: (float32 [B, obs_dim], uint8 [B, n_actions])."""
         c = self.holder.struct

@@ -223,6 +223,36 @@ def test_observation_per_link_attenuation_vs_oracle():
     assert mask[:, :-1].any() and not mask[:, :-1].all()
 
 
+def test_sample_actions_uniform_over_the_mask():
+    """ongym_sample_actions = gymnasium's action_space.sample(mask): always a valid action, deterministic in (seed, draw),
+    uniform over the valid ones (chi-square on a replica with few valid actions), reject when nothing else is valid."""
+    env = BatchedQRMSAEnv(tables=golden_tables("nsfnet"), modulations=jocn_modulations(), batch_size=16,
+                          num_spectrum_resources=320, capacity=1024, load=2000, bit_rate_selection="discrete",
+                          bit_rates=(10, 40, 100, 400))
+    env.seed(3); env.reset(); env.step_policy(900, record=False)
+    obs, mask = env.observe()
+    rng = np.random.default_rng(0)
+    mask2 = mask.copy()
+    mask2[0, :-1] = 0                                   # only the reject action
+    keep = rng.choice(np.flatnonzero(mask[1]), size=min(11, int(mask[1].sum())), replace=False)
+    mask2[1, :] = 0; mask2[1, keep] = 1                 # 11 valid actions at arbitrary positions
+    mask2[2, :] = 0; mask2[2, [0, 1, 2, 3, 9597, 9598, 9599, 9600]] = 1     # head / tail bytes of the row
+    a = env.sample_actions(mask2, 5, 0)
+    assert np.array_equal(a, env.sample_actions(mask2, 5, 0)) and a[0] == env.reject_action
+    assert mask2[np.arange(16), a].all()
+    counts1, counts2 = {}, {}
+    n = 3000
+    for d in range(n):
+        a = env.sample_actions(mask2, 5, d)
+        assert mask2[np.arange(16), a].all()
+        counts1[int(a[1])] = counts1.get(int(a[1]), 0) + 1
+        counts2[int(a[2])] = counts2.get(int(a[2]), 0) + 1
+    for counts, k in ((counts1, len(keep)), (counts2, 8)):
+        assert len(counts) == k
+        chi2 = sum((c - n / k) ** 2 / (n / k) for c in counts.values())
+        assert chi2 < 40, counts                         # 10 / 7 degrees of freedom: p(chi2 > 40) < 1e-4
+
+
 def test_masked_actions_are_accepted_by_step():
     """every action the mask allows is feasible: stepping it never raises the QoT error / retry."""
     meta, d = load_traj("obs_nsfnet320_dense")

@@ -1152,65 +1152,84 @@ def test_long_wide_sweep_final_state_vs_oracle():
     assert blocked > 50000          # the sweep does reach heavily blocked regimes
 
 
-def test_caller_stream_equals_own_stream():
-    """ongym_set_stream: observe -> torch ops -> step on torch's current stream with NO host synchronisation in between gives
-    the records of the same loop run on the environment's own stream with a synchronisation after every call."""
-    import torch
-    tb = golden_tables("nsfnet")
-    B, steps = 256, 40
-    kw = dict(tables=tb, modulations=jocn_modulations(), batch_size=B, num_spectrum_resources=320, capacity=448, load=300,
-              bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), episode_length=1000, io_device=True)
-    dev = torch.device("cuda", 0)
-    out = []
-    for shared in (False, True):
-        env = BatchedQRMSAEnv(**kw)
-        c = env.holder.struct
-        obs = torch.empty((B, 3 + c.k_paths + c.k_paths * c.n_mods_consider * 12), dtype=torch.float32, device=dev)
-        mask = torch.empty((B, c.k_paths * c.n_mods_consider * c.n_slots + 1), dtype=torch.uint8, device=dev)
-        actions = torch.empty(B, dtype=torch.int32, device=dev)
-        recs = torch.empty((steps, B, nat.STEP_DTYPE.itemsize), dtype=torch.uint8, device=dev)
-        env.seed(3); env.reset()
-        env.step_policy(300, record=False); env.sync()
-        stream = torch.cuda.Stream(device=dev)
-        with torch.cuda.stream(stream):
-            if shared:
-                env.set_stream(stream.cuda_stream)
-            for i in range(steps):
-                env._check(env.lib.ongym_observe(env._h, obs.data_ptr(), mask.data_ptr()), "observe")
-                if not shared:
-                    env.sync()
-                # the lowest allowed action of every replica (deterministic), computed by torch on the same stream
-                actions.copy_(torch.argmax(mask, dim=1))
-                if not shared:
-                    stream.synchronize()
-                env._check(env.lib.ongym_step_actions(env._h, actions.data_ptr(), recs[i].data_ptr()), "step")
-                if not shared:
-                    env.sync()
-            stream.synchronize()
-            if shared:
-                env.set_stream(None)
-        out.append(recs.cpu().numpy().view(nat.STEP_DTYPE).reshape(steps, B).copy())
-        assert out[-1]["accepted"].mean() > 0.5
-    for f in nat.STEP_DTYPE.names:       # (field by field: the records' padding bytes are not written)
-        assert np.array_equal(out[0][f], out[1][f]), f
-    # ... and on the DEFAULT stream (handle 0), which is what torch.cuda.current_stream() is unless the caller changed it
+_STREAM_SCRIPT = r'''
+import sys
+sys.path[:0] = [%r, %r]
+import numpy as np
+from common import golden_tables, jocn_modulations
+from optical_networking_gym import _native as nat
+from optical_networking_gym.envs.batched import BatchedQRMSAEnv
+import torch
+tb = golden_tables("nsfnet")
+B, steps = 256, 40
+kw = dict(tables=tb, modulations=jocn_modulations(), batch_size=B, num_spectrum_resources=320, capacity=448, load=300,
+          bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), episode_length=1000, io_device=True)
+dev = torch.device("cuda", 0)
+out = []
+for shared in (False, True):
     env = BatchedQRMSAEnv(**kw)
-    env.seed(3); env.reset(); env.step_policy(300, record=False); env.sync()
-    assert torch.cuda.current_stream().cuda_stream == 0
-    env.set_stream(torch.cuda.current_stream().cuda_stream)
     c = env.holder.struct
     obs = torch.empty((B, 3 + c.k_paths + c.k_paths * c.n_mods_consider * 12), dtype=torch.float32, device=dev)
     mask = torch.empty((B, c.k_paths * c.n_mods_consider * c.n_slots + 1), dtype=torch.uint8, device=dev)
     actions = torch.empty(B, dtype=torch.int32, device=dev)
     recs = torch.empty((steps, B, nat.STEP_DTYPE.itemsize), dtype=torch.uint8, device=dev)
-    for i in range(steps):
-        env._check(env.lib.ongym_observe(env._h, obs.data_ptr(), mask.data_ptr()), "observe")
-        actions.copy_(torch.argmax(mask, dim=1))
-        env._check(env.lib.ongym_step_actions(env._h, actions.data_ptr(), recs[i].data_ptr()), "step")
-    torch.cuda.synchronize()
-    got = recs.cpu().numpy().view(nat.STEP_DTYPE).reshape(steps, B)
-    for f in nat.STEP_DTYPE.names:
-        assert np.array_equal(got[f], out[0][f]), f
+    env.seed(3); env.reset()
+    env.step_policy(300, record=False); env.sync()
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        if shared:
+            env.set_stream(stream.cuda_stream)
+        for i in range(steps):
+            env._check(env.lib.ongym_observe(env._h, obs.data_ptr(), mask.data_ptr()), "observe")
+            if not shared:
+                env.sync()
+            # the lowest allowed action of every replica (deterministic), computed by torch on the same stream
+            actions.copy_(torch.argmax(mask, dim=1))
+            if not shared:
+                stream.synchronize()
+            env._check(env.lib.ongym_step_actions(env._h, actions.data_ptr(), recs[i].data_ptr()), "step")
+            if not shared:
+                env.sync()
+        stream.synchronize()
+        if shared:
+            env.set_stream(None)
+    out.append(recs.cpu().numpy().view(nat.STEP_DTYPE).reshape(steps, B).copy())
+    assert out[-1]["accepted"].mean() > 0.5
+for f in nat.STEP_DTYPE.names:       # (field by field: the records' padding bytes are not written)
+    assert np.array_equal(out[0][f], out[1][f]), f
+# ... and on the DEFAULT stream (handle 0), which is what torch.cuda.current_stream() is unless the caller changed it
+env = BatchedQRMSAEnv(**kw)
+env.seed(3); env.reset(); env.step_policy(300, record=False); env.sync()
+assert torch.cuda.current_stream().cuda_stream == 0
+env.set_stream(torch.cuda.current_stream().cuda_stream)
+c = env.holder.struct
+obs = torch.empty((B, 3 + c.k_paths + c.k_paths * c.n_mods_consider * 12), dtype=torch.float32, device=dev)
+mask = torch.empty((B, c.k_paths * c.n_mods_consider * c.n_slots + 1), dtype=torch.uint8, device=dev)
+actions = torch.empty(B, dtype=torch.int32, device=dev)
+recs = torch.empty((steps, B, nat.STEP_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+for i in range(steps):
+    env._check(env.lib.ongym_observe(env._h, obs.data_ptr(), mask.data_ptr()), "observe")
+    actions.copy_(torch.argmax(mask, dim=1))
+    env._check(env.lib.ongym_step_actions(env._h, actions.data_ptr(), recs[i].data_ptr()), "step")
+torch.cuda.synchronize()
+got = recs.cpu().numpy().view(nat.STEP_DTYPE).reshape(steps, B)
+for f in nat.STEP_DTYPE.names:
+    assert np.array_equal(got[f], out[0][f]), f
+print("stream test ok")
+'''
+
+
+def test_caller_stream_equals_own_stream(tmp_path):
+    """ongym_set_stream: observe -> torch ops -> step on torch's current stream with NO host synchronisation in between gives
+    the records of the same loop run on the environment's own stream with a synchronisation after every call.  Runs in a fresh
+    process: PyTorch brings its own copy of the HIP runtime, which refuses to initialise late in a process that has already
+    created and destroyed a few hundred streams through the system's one."""
+    import os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "stream_test.py"
+    script.write_text(_STREAM_SCRIPT % (os.path.join(repo, "optical-networking-gym_amd"), os.path.join(repo, "tests")))
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "stream test ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
 def test_action_above_the_reject_index_wraps_like_the_reference():

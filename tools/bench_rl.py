@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=300, help="first-fit steps that fill the network before the loop")
     ap.add_argument("--learner", action="store_true")
     ap.add_argument("--horizon", type=int, default=16)
+    ap.add_argument("--torch-sampler", action="store_true", help="masked sampling with torch ops instead of ongym_sample_actions")
     ap.add_argument("--own-stream", action="store_true", help="round-2 behaviour: env on its own stream, three host syncs per step")
     args = ap.parse_args()
     if "RANK" not in os.environ and args.gpus > 1:
@@ -125,9 +126,15 @@ def main():
                                    right=True).squeeze(1)
         return torch.where(bi >= nblk, torch.full_like(r, nact - 1), (bic * 64 + inner).to(torch.int32))
 
+    draw = [0]
+
     def rl_step():
         env_observe()
-        actions.copy_(sample_masked())                                        # masked random policy
+        if args.torch_sampler:
+            actions.copy_(sample_masked())                                    # masked random policy, torch ops
+        else:                                                                 # ... or the library's sampler (one small kernel)
+            env._check(env.lib.ongym_sample_actions(env._h, mask.data_ptr(), 7, draw[0], actions.data_ptr()), "sample")
+            draw[0] += 1
         env_step()
 
     if args.learner:
