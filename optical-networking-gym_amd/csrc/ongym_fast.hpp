@@ -787,12 +787,22 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             // LOWEST_FRAGMENTATION stops at the first that passes.
             auto eval_cands = [&](int cnt, int nn, int m, int q, const PathRec &pr, int k, int path, uint64_t pmask, double l_nlic,
                                   double l_selfa, double l_lo, double l_hi) -> bool {
-                constexpr int NA = 2, TU = 4;
+#ifndef ONGYM_CAND_NA
+#define ONGYM_CAND_NA 2
+#endif
+#ifndef ONGYM_CAND_TU
+#define ONGYM_CAND_TU 4
+#endif
+                constexpr int NA = ONGYM_CAND_NA, TU = ONGYM_CAND_TU;
                 const double c_bw = P.slot_bw * nn, c_h = P.slot_bw * (nn / 2.0);
                 const double c_nlic = readlane_f64(l_nlic, q), c_self = pr.w1 * readlane_f64(l_selfa, q);
                 const double c_lo = readlane_f64(l_lo, q), c_hi = readlane_f64(l_hi, q);
+#ifdef ONGYM_X_REVERSE_PASSES
+                for (int j0 = ((cnt - 1) / (NA * kWave)) * (NA * kWave); j0 >= 0; j0 -= NA * kWave) {
+#else
                 for (int j0 = 0; j0 < cnt; j0 += NA * kWave) {
-                    const bool two = j0 + kWave < cnt;          // the second chunk holds candidates (wave-uniform)
+#endif
+                    const bool two = NA > 1 && j0 + kWave < cnt;          // the second chunk holds candidates (wave-uniform)
                     uint32_t ss[NA], xs[NA];
                     double f[NA], gase[NA];
                     bool live[NA];
@@ -836,11 +846,18 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
     #pragma unroll
                                 for (int a = 0; a < NA; a++)
                                     if (a == 0 || two) f[a] = fma(tp[u][a].x, w[u].x, fma(-tp[u][a].y, w[u].y, f[a]));
-                            if ((t & 15) == 12 && base + t + TU < L) {      // every 16 interferers: can any candidate still matter?
-                                bool alive = live[0] && gase[0] + c_nlic * (f[0] + c_self) < thr;
-                                if (two) alive |= live[1] && gase[1] + c_nlic * (f[1] + c_self) < thr;
+    #ifndef ONGYM_X_NO_EARLY_EXIT
+#ifndef ONGYM_EXIT_EVERY
+#define ONGYM_EXIT_EVERY 4
+#endif
+                            if (((t + TU) & (ONGYM_EXIT_EVERY - 1)) == 0 && base + t + TU < L) {      // every ONGYM_EXIT_EVERY interferers: can any candidate still matter?
+                                bool alive = false;
+#pragma unroll
+                                for (int a = 0; a < NA; a++)
+                                    if (a == 0 || two) alive |= live[a] && gase[a] + c_nlic * (f[a] + c_self) < thr;
                                 if (!__ballot(alive)) { cut = true; break; }
                             }
+#endif
                         }
                         wave_sync();                            // the stage is rewritten by the next block
                     }

@@ -6,7 +6,7 @@ import os
 import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(REPO, "optical-networking-gym_amd"), REPO]
-os.environ["ONGYM_HIP_LIB"] = os.path.join(REPO, "optical-networking-gym_amd", "csrc", "libongym_hip_stamps.so")
+os.environ["ONGYM_HIP_LIB"] = os.path.join(REPO, "optical-networking-gym_amd", "csrc", "variants", "lib_stamps.so")
 import numpy as np  # noqa: E402
 import bench  # noqa: E402
 from optical_networking_gym.envs.batched import BatchedQRMSAEnv  # noqa: E402
