@@ -257,6 +257,13 @@ int ongym_reset_episode_counters(ongym_env *env, const uint8_t *mask);
 int ongym_step_policy(ongym_env *env, int32_t policy, int32_t nsteps, ongym_step_rec *out);
 /* QRMSAEnv.step(action) (qrmsa.pyx:838-1065) with caller-supplied actions[batch]. out: [batch] or NULL. */
 int ongym_step_actions(ongym_env *env, const int32_t *actions, ongym_step_rec *out);
+/* The loop body of the reference's drivers (graph_load.py:157-164: `action = heuristic(env); env.step(action)`) for callers that
+ * hold ONE environment and need every result on the host: ongym_step_actions(actions), then - on the same stream, with no host
+ * round trip in between - fused policy `next_policy` evaluated on the NEW current request (as ongym_policy_actions; a negative
+ * id skips it), and step records [batch], the new requests [batch], the statistics [batch] and the next actions / flags [batch]
+ * come back together behind ONE synchronisation (host buffers only; next_actions / next_flags may be NULL when next_policy < 0). */
+int ongym_step_actions_bundle(ongym_env *env, const int32_t *actions, int32_t next_policy, ongym_step_rec *rec_out,
+                              ongym_request *request_out, ongym_stats *stats_out, int32_t *next_actions, uint8_t *next_flags);
 /* The heuristic alone, without stepping: actions[batch], flags[batch] (ONGYM_F_BLOCKED_*) (heuristics.py:923-966). */
 int ongym_policy_actions(ongym_env *env, int32_t policy, int32_t *actions, uint8_t *flags);
 

@@ -30,7 +30,8 @@ constexpr int kMaxRowWords = 16;   // n_slots <= 1023 (+1 virtual guard bit)
 constexpr int kMaxLinks = 128;     // two 64-bit link-mask words per path
 constexpr int kMaxHops = 64;       // one lane per hop
 
-enum RunMode { kModePolicyStep = 0, kModeActionStep = 1, kModePolicyOnly = 2 };
+enum RunMode { kModePolicyStep = 0, kModeActionStep = 1, kModePolicyOnly = 2,
+               kModeActionThenPolicy = 3 };   // one launch: step(actions), then the policy alone on the new request (nsteps = 2)
 enum ReqMode { kReqNone = 0, kReqRng = 1, kReqTrace = 2 };
 
 struct DevEnv {

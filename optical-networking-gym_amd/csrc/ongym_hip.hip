@@ -29,7 +29,7 @@ using namespace ongym;
 constexpr int kPolicyMisc = 3;   // template value of the shared instantiation for policy ids >= ONGYM_POLICY_LOWEST_SPECTRUM
 
 template <bool UA, bool R32, int WAVES, int POLICY, bool DEFRAG = false>
-__global__ __launch_bounds__(64, WAVES) void k_run(const Params *__restrict__ Pp, int mode, int nsteps, const int32_t *actions, int32_t *act_out,
+__global__ __launch_bounds__(64, WAVES) void k_run(const Params *__restrict__ Pp, int run_mode, int nsteps, const int32_t *actions, int32_t *act_out,
                                             uint8_t *flag_out, ongym_step_rec *out, int policy_id) {
     extern __shared__ __align__(16) unsigned char smem[];
     const Params &P = *Pp;
@@ -56,7 +56,10 @@ __global__ __launch_bounds__(64, WAVES) void k_run(const Params *__restrict__ Pp
     STAMP(c, 8);
     for (int it = 0; it < nsteps; ++it) {
         DevEnv *e = c.e;
-        ongym_step_rec *rec = out ? out + (size_t)it * P.batch + c.replica : nullptr;
+        // kModeActionThenPolicy (the single-environment surface, ongym_step_actions_bundle): iteration 0 applies the action,
+        // iteration 1 evaluates the policy on the request that step drew - the same code, no second launch
+        const int mode = run_mode == kModeActionThenPolicy ? (it == 0 ? kModeActionStep : kModePolicyOnly) : run_mode;
+        ongym_step_rec *rec = (out && mode != kModePolicyOnly) ? out + (size_t)it * P.batch + c.replica : nullptr;
         if (!e->have_request) {   // no request source / trace exhausted: the step is a no-op
             if (c.lane == 0) {
                 e->st.flags |= ONGYM_F_NO_REQUEST;
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(64, WAVES) void k_run(const Params *__restrict__ Pp
         }
         apply_step<R32, DEFRAG>(c, ch, outcome, rec);
     }
-    if (mode != kModePolicyOnly) store_state(c);
+    if (run_mode != kModePolicyOnly) store_state(c);
     STAMP(c, 9);
 #ifdef ONGYM_STAMPS
     if (c.lane == 0 && P.dbg)
@@ -823,6 +826,7 @@ void ongym_destroy(ongym_env *env) {
     for (void *p : env->allocs) (void)hipFree(p);
     if (env->d_trace) (void)hipFree(env->d_trace);
     if (env->d_out) (void)hipFree(env->d_out);
+    if (env->h_pinned) (void)hipHostFree(env->h_pinned);
     if (env->ev0) (void)hipEventDestroy(env->ev0);
     if (env->ev1) (void)hipEventDestroy(env->ev1);
     if (env->own_stream) (void)hipStreamDestroy(env->own_stream);      // a caller's stream (ongym_set_stream) is the caller's
@@ -1142,6 +1146,77 @@ int ongym_step_actions(ongym_env *env, const int32_t *actions, ongym_step_rec *o
         HIP_TRY(env, hipMemcpyAsync(out, env->d_out, (size_t)env->P.batch * sizeof(ongym_step_rec), hipMemcpyDeviceToHost, env->stream));
     } else if ((rc = launch_run(env, kModeActionStep, ONGYM_POLICY_FIRST_FIT, 1, env->d_actions, nullptr, nullptr, nullptr))) return rc;
     HIP_TRY(env, hipStreamSynchronize(env->stream));
+    return ONGYM_OK;
+}
+
+static int check_policy(ongym_env *env, int32_t policy) {
+    if (policy < ONGYM_POLICY_FIRST_FIT || policy >= ONGYM_POLICY_COUNT) return fail_arg(env, "unknown policy id");
+    if (policy >= ONGYM_POLICY_LOWEST_SPECTRUM && env->P.k_paths > 8)
+        return fail_arg(env, "this policy supports at most 8 candidate routes", ONGYM_E_LIMIT);
+    if (policy != ONGYM_POLICY_FIRST_FIT && env->P.n_mods_consider < env->P.n_mods)
+        return fail_arg(env, "only the first-fit policy is fused for modulations_to_consider < n_mods", ONGYM_E_LIMIT);
+    if (policy == ONGYM_POLICY_MSCL && (env->P.bit_rate_mode != 0 || env->P.n_bit_rates <= 0))
+        return fail_arg(env, "the MSCL policy sums its capacity loss over the discrete bit rates: bit_rate_mode must be discrete", ONGYM_E_LIMIT);
+    return 0;
+}
+
+int ongym_step_actions_bundle(ongym_env *env, const int32_t *actions, int32_t next_policy, ongym_step_rec *rec_out,
+                              ongym_request *request_out, ongym_stats *stats_out, int32_t *next_actions, uint8_t *next_flags) {
+    if (!env || !actions || !rec_out || !request_out || !stats_out) return env ? fail_arg(env, "null buffer") : ONGYM_E_ARG;
+    if (env->cfg.io_device) return fail_arg(env, "ongym_step_actions_bundle returns host buffers: not with io_device", ONGYM_E_STATE);
+    if (next_policy >= 0 && (!next_actions || !next_flags)) return fail_arg(env, "null next_actions / next_flags");
+    if (!env->has_source) { env->err = "no request source: call ongym_seed or ongym_set_requests first"; return ONGYM_E_STATE; }
+    int rc;
+    if (next_policy >= 0 && (rc = check_policy(env, next_policy))) return rc;
+    HIP_TRY(env, hipSetDevice(env->cfg.device));
+    const size_t B = (size_t)env->P.batch;
+    // pinned staging: records | DevEnv (requests + statistics) | next actions | next flags | actions in
+    const size_t o_rec = 0, o_env = o_rec + B * sizeof(ongym_step_rec), o_act = o_env + B * sizeof(DevEnv),
+                 o_flag = o_act + B * sizeof(int32_t), o_in = o_flag + ((B + 15) & ~(size_t)15), total = o_in + B * sizeof(int32_t);
+    if (env->h_pinned_bytes < total) {
+        if (env->h_pinned) { (void)hipHostFree(env->h_pinned); env->h_pinned = nullptr; env->h_pinned_bytes = 0; }
+        HIP_TRY(env, hipHostMalloc(&env->h_pinned, total, hipHostMallocDefault));
+        env->h_pinned_bytes = total;
+    }
+    char *hp = static_cast<char *>(env->h_pinned);
+    if (B <= 256) {
+        // few replicas (the single-environment surface): the kernels read the actions from and write their results to the
+        // pinned host buffer directly (it is device-accessible): launches and one synchronisation, no copy calls for them
+        int32_t *h_act_in = reinterpret_cast<int32_t *>(hp + o_in);
+        memcpy(h_act_in, actions, B * 4);
+        if (next_policy >= 0)
+            rc = launch_run(env, kModeActionThenPolicy, next_policy, 2, h_act_in, reinterpret_cast<int32_t *>(hp + o_act),
+                            reinterpret_cast<uint8_t *>(hp + o_flag), reinterpret_cast<ongym_step_rec *>(hp + o_rec));
+        else
+            rc = launch_run(env, kModeActionStep, ONGYM_POLICY_FIRST_FIT, 1, h_act_in, nullptr, nullptr,
+                            reinterpret_cast<ongym_step_rec *>(hp + o_rec));
+        if (rc) return rc;
+        HIP_TRY(env, hipMemcpyAsync(hp + o_env, env->P.env, B * sizeof(DevEnv), hipMemcpyDeviceToHost, env->stream));
+    } else {
+        if ((rc = ensure_out(env, B))) return rc;
+        HIP_TRY(env, hipMemcpyAsync(env->d_actions, actions, B * 4, hipMemcpyHostToDevice, env->stream));
+        if ((rc = launch_run(env, kModeActionStep, ONGYM_POLICY_FIRST_FIT, 1, env->d_actions, nullptr, nullptr, env->d_out))) return rc;
+        if (next_policy >= 0 && (rc = launch_run(env, kModePolicyOnly, next_policy, 1, nullptr, env->d_act_out, env->d_flag_out, nullptr))) return rc;
+        HIP_TRY(env, hipMemcpyAsync(hp + o_rec, env->d_out, B * sizeof(ongym_step_rec), hipMemcpyDeviceToHost, env->stream));
+        HIP_TRY(env, hipMemcpyAsync(hp + o_env, env->P.env, B * sizeof(DevEnv), hipMemcpyDeviceToHost, env->stream));
+        if (next_policy >= 0) {
+            HIP_TRY(env, hipMemcpyAsync(hp + o_act, env->d_act_out, B * 4, hipMemcpyDeviceToHost, env->stream));
+            HIP_TRY(env, hipMemcpyAsync(hp + o_flag, env->d_flag_out, B, hipMemcpyDeviceToHost, env->stream));
+        }
+    }
+    HIP_TRY(env, hipStreamSynchronize(env->stream));
+    memcpy(rec_out, hp + o_rec, B * sizeof(ongym_step_rec));
+    const DevEnv *de = reinterpret_cast<const DevEnv *>(hp + o_env);
+    int flags = 0;
+    for (size_t r = 0; r < B; r++) {
+        stats_out[r] = de[r].st; flags |= de[r].st.flags;
+        ongym_request &q = request_out[r];
+        memset(&q, 0, sizeof(q));
+        q.arrival_time = de[r].cur_at; q.holding_time = de[r].cur_ht; q.bit_rate = de[r].cur_br;
+        q.source = (int16_t)de[r].cur_src; q.destination = (int16_t)de[r].cur_dst;
+    }
+    if (next_policy >= 0) { memcpy(next_actions, hp + o_act, B * 4); memcpy(next_flags, hp + o_flag, B); }
+    if (flags & ONGYM_F_OVERFLOW) { env->err = "a replica overflowed its service table (raise capacity)"; return ONGYM_E_CAPACITY; }
     return ONGYM_OK;
 }
 

@@ -26,6 +26,7 @@ struct ongym_env {
     int32_t *d_actions = nullptr; int32_t *d_act_out = nullptr; uint8_t *d_flag_out = nullptr; uint8_t *d_mask = nullptr;
     float *d_obs = nullptr; uint8_t *d_obsmask = nullptr;   // lazily allocated staging for ongym_observe with host buffers
     int32_t *d_scratch_i = nullptr; size_t scratch_i_bytes = 0; double *d_scratch_d = nullptr;
+    void *h_pinned = nullptr; size_t h_pinned_bytes = 0;     // pinned staging of ongym_step_actions_bundle
     bool has_source = false;
     uint64_t replica_base = 0;      // global index of this environment's first replica (ongym_seed_base)
     std::vector<double> cfg_bit_rates;     // host copy of the discrete bit rates

@@ -202,6 +202,9 @@ def _declare(lib):
     lib.ongym_step_policy.argtypes = [vp, C.c_int32, C.c_int32, vp]
     lib.ongym_step_actions.argtypes = [vp, vp, vp]
     lib.ongym_policy_actions.argtypes = [vp, C.c_int32, vp, vp]
+    if hasattr(lib, "ongym_step_actions_bundle"):
+        lib.ongym_step_actions_bundle.argtypes = [vp, vp, C.c_int32, vp, vp, vp, vp, vp]
+        lib.ongym_step_actions_bundle.restype = C.c_int32
     lib.ongym_observe.argtypes = [vp, vp, vp]
     if hasattr(lib, "ongym_sample_actions"):
         lib.ongym_sample_actions.argtypes = [vp, vp, C.c_uint64, C.c_uint64, vp]
@@ -246,7 +249,7 @@ def _declare_tail(lib, vp, skip=()):
 
 EXPORTED_SYMBOLS = (
     "ongym_create", "ongym_destroy", "ongym_seed", "ongym_seed_base", "ongym_set_requests", "ongym_reset", "ongym_reset_episode_counters", "ongym_step_policy",
-    "ongym_step_actions", "ongym_policy_actions", "ongym_observe", "ongym_sample_actions", "ongym_query_available", "ongym_query_gsnr", "ongym_query_gsnr_many", "ongym_query_moves", "ongym_query_grid",
+    "ongym_step_actions", "ongym_step_actions_bundle", "ongym_policy_actions", "ongym_observe", "ongym_sample_actions", "ongym_query_available", "ongym_query_gsnr", "ongym_query_gsnr_many", "ongym_query_moves", "ongym_query_grid",
     "ongym_query_services", "ongym_query_request", "ongym_query_candidates", "ongym_query_path_free",
     "ongym_stats_get", "ongym_sync", "ongym_set_stream", "ongym_last_kernel_ms", "ongym_query_occupancy", "ongym_query_occupancy_policy",
     "ongym_last_error", "ongym_abi_version", "ongym_sizeof")

@@ -138,6 +138,21 @@ class BatchedQRMSAEnv:
         self._check(self.lib.ongym_step_actions(self._h, actions.ctypes.data, out.ctypes.data), "ongym_step_actions")
         return out
 
+    def step_bundle(self, actions: np.ndarray, next_policy: int = -1):
+        """`step(actions)`, then fused policy `next_policy` on the new current requests (skipped when negative), everything
+        behind one synchronisation (ongym_step_actions_bundle): (records, requests, stats, next_actions | None, next_flags | None)."""
+        actions = np.ascontiguousarray(actions, np.int32)
+        if actions.shape != (self.batch_size,):
+            raise ValueError("actions must have one entry per replica")
+        B = self.batch_size
+        rec, req, st = np.zeros(B, nat.STEP_DTYPE), np.zeros(B, nat.REQUEST_DTYPE), np.zeros(B, nat.STATS_DTYPE)
+        na, nf = (np.zeros(B, np.int32), np.zeros(B, np.uint8)) if next_policy >= 0 else (None, None)
+        self._check(self.lib.ongym_step_actions_bundle(self._h, actions.ctypes.data, int(next_policy), rec.ctypes.data,
+                                                       req.ctypes.data, st.ctypes.data,
+                                                       na.ctypes.data if na is not None else None,
+                                                       nf.ctypes.data if nf is not None else None), "ongym_step_actions_bundle")
+        return rec, req, st, na, nf
+
     def policy_actions(self, policy: int = nat.POLICY_FIRST_FIT):
         actions = np.zeros(self.batch_size, np.int32)
         flags = np.zeros(self.batch_size, np.uint8)

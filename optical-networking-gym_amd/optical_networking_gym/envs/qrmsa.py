@@ -227,6 +227,9 @@ class QRMSAEnv:
             self.file_stats.write("id,source,destination,bit_rate,path_k,path_length,modulation,min_osnr,osnr,ase,nli,"
                                   "disrupted_services,active_services\n")
         self._disrupted_seen = 0
+        self._sticky_policy, self._policy_cache = -1, None     # see policy_action / step
+        self._modulation_keys = ["modulation_{}".format(str(float(m.spectral_efficiency))) for m in self.modulations]
+        self._action_buf = np.zeros(1, np.int32)
         self.current_service: Optional[Service] = None
         self.current_time = 0.0
         self._last_stats = None
@@ -234,9 +237,10 @@ class QRMSAEnv:
             self.reset()
 
     # ---- views ---------------------------------------------------------------------------------------------------
-    def _pull_request(self):
-        q = self._dev.request(0)
-        st = self._dev.stats()[0]
+    def _pull_request(self, q=None, st=None):
+        if q is None:
+            q = self._dev.request(0)
+            st = self._dev.stats()[0]
         self._last_stats = st
         self.current_time = float(st["current_time"])
         src, dst = int(q["source"]), int(q["destination"])
@@ -301,6 +305,7 @@ class QRMSAEnv:
             if not self._tracks_ids:
                 raise NotImplementedError("only_episode_counters needs service ids on device (uniform attenuation)")
             self._dev.reset_episode_counters()
+            self._policy_cache = None          # service ids restart: the GN model's "self" skip (core/osnr.pyx:65) may decide otherwise
             self.max_modulation_idx = len(self.modulations) - 1
             self._last_stats = self._dev.stats()[0]
             obs, _ = self._blank_observation()
@@ -321,7 +326,12 @@ class QRMSAEnv:
     def step(self, action: int):
         cur = self.current_service
         running_before = len(self._dev.services(0)) if self.file_stats is not None else 0
-        rec = self._dev.step(np.array([int(action)], np.int32))[0]
+        # one call: the step, the next request, the statistics and - for the fused heuristic the caller used last - the next
+        # decision (graph_load.py:157-164 calls heuristic(env) and env.step(action) in turn: one synchronisation per iteration)
+        self._policy_cache = None
+        self._action_buf[0] = int(action)
+        recs, reqs, sts, nacts, nflags = self._dev.step_bundle(self._action_buf, self._sticky_policy)
+        rec = recs[0]
         obs, mask = (None, None) if (rec["flags"] & (nat.F_QOT_ERROR | nat.F_NO_REQUEST)) else self._blank_observation()
         if rec["flags"] & nat.F_QOT_ERROR:
             route, mod_idx, slot = self.encoded_decimal_to_array(int(action))
@@ -366,8 +376,10 @@ class QRMSAEnv:
                                                + self.frequency_slot_bandwidth * (listed.number_slots / 2.0))
                     listed.launch_power = self.launch_power
                     listed.OSNR, listed.ASE, listed.NLI = float(mv["osnr"]), float(mv["ase"]), float(mv["nli"])
-        self._pull_request()
+        self._pull_request(reqs[0], sts[0])
         self._refresh_views()
+        if nacts is not None and not rec["retry"]:
+            self._policy_cache = (self._sticky_policy, self._state_version, int(nacts[0]), int(nflags[0]))
         st = self._last_stats
         terminated = bool(rec["terminated"])
         if self.file_stats is not None:   # qrmsa.pyx:967-990
@@ -408,8 +420,9 @@ class QRMSAEnv:
             info["episode_service_blocking_rate"] = float(st["last_episode_service_blocking_rate"])
             info["bit_rate_blocking_rate"] = float(st["last_bit_rate_blocking_rate"])
             info["episode_bit_rate_blocking_rate"] = float(st["last_episode_bit_rate_blocking_rate"])
-        for m, modulation in enumerate(self.modulations):
-            info["modulation_{}".format(str(float(modulation.spectral_efficiency)))] = int(st["episode_modulation_hist"][m])
+        hist = st["episode_modulation_hist"]
+        for m, key in enumerate(self._modulation_keys):
+            info[key] = int(hist[m])
         if terminated:
             info["blocked_due_to_resources"] = 0   # always 0 in the reference (quirk Q6)
             info["blocked_due_to_osnr"] = 0
@@ -546,8 +559,14 @@ class QRMSAEnv:
 
     def policy_action(self, policy: int = nat.POLICY_FIRST_FIT):
         """A fused device policy evaluated on the current request: (action, blocked_resources, blocked_osnr)."""
-        a, f = self._dev.policy_actions(policy)
-        return int(a[0]), bool(f[0] & nat.F_BLOCKED_RESOURCES), bool(f[0] & nat.F_BLOCKED_OSNR)
+        c = self._policy_cache
+        if c is not None and c[0] == policy and c[1] == self._state_version:     # decided by the last step's bundle
+            a0, f0 = c[2], c[3]
+        else:
+            a, f = self._dev.policy_actions(policy)
+            a0, f0 = int(a[0]), int(f[0])
+        self._sticky_policy = int(policy)      # the next step() asks the device for this policy's next decision in the same call
+        return a0, bool(f0 & nat.F_BLOCKED_RESOURCES), bool(f0 & nat.F_BLOCKED_OSNR)
 
     def first_fit_action(self):
         """heuristic_shortest_available_path_first_fit_best_modulation (heuristics.py:923-966) on device."""

@@ -180,6 +180,35 @@ def test_gen_observation_through_the_wrapper():
         obs, reward, done, truncated, info = env.step(int(d["action"][i]))
 
 
+def test_step_bundle_prefetches_the_next_decision():
+    """QRMSAEnv.step() asks the device for the next decision of the fused heuristic the caller used last in the same call
+    (ongym_step_actions_bundle: one synchronisation per loop iteration of graph_load.py:157-164); the prefetched decision must
+    be the one a fresh policy call gives, also when the caller switches heuristics, resets or retries."""
+    from optical_networking_gym import _native as nat
+    topology = get_topology(bundled_topology_path("nsfnet_chen.txt"), None, jocn_modulations(), 80, 0.2, 4.5, 5)
+    env = QRMSAEnvWrapper(topology=topology, seed=3, load=1500, episode_length=120, num_spectrum_resources=320,
+                          bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), gen_observation=False)
+    sim = get_qrmsa_env(env)
+    env.reset()
+    hits = 0
+    for i in range(400):
+        pid = nat.POLICY_LOAD_BALANCING if (i // 50) % 2 else nat.POLICY_FIRST_FIT
+        fresh_a, fresh_f = sim._dev.policy_actions(pid)
+        cached = sim._policy_cache is not None and sim._policy_cache[0] == pid and sim._policy_cache[1] == sim._state_version
+        hits += int(cached)
+        a, bres, bosnr = sim.policy_action(pid)
+        assert a == int(fresh_a[0]) and bres == bool(fresh_f[0] & nat.F_BLOCKED_RESOURCES) and bosnr == bool(fresh_f[0] & nat.F_BLOCKED_OSNR)
+        if i % 37 == 5:            # an occupied-slots action: penalty, the same request stays (quirk Q5), nothing may be cached
+            busy = np.where(sim.get_available_slots(sim.k_shortest_paths[sim.current_service.source, sim.current_service.destination][0]) == 0)[0]
+            if len(busy):
+                env.step(int(busy[0]))
+                assert sim._policy_cache is None
+        _, _, done, _, _ = env.step(a)
+        if done:
+            env.reset()
+    assert hits > 300
+
+
 def test_bands_with_gen_observation_through_the_wrapper():
     """The reference's own driver passes bands=[S, C, L] (graph_launch_power.py:102) and its observation runs with it: one slot
     per service (quirk Q9), frequencies from channel_width.  QRMSAEnvWrapper(bands=..., gen_observation=True) against the

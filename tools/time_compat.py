@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Steps/s of the single-environment compatibility surface (QRMSAEnvWrapper + the heuristics plugin API), i.e. what an
-unmodified reference script sees: one device launch per heuristic call and per env.step().
+unmodified reference script sees: env.step() brings the next request, the statistics and the next decision of the
+fused heuristic back in one call (ongym_step_actions_bundle); round 2: one launch + copy per heuristic call and per step.
     python tools/time_compat.py [steps]"""
 import os
 import sys
