@@ -27,16 +27,19 @@ static size_t lds_of(const ongym_env *env) {
     return fast_lds_bytes(env->P.n_links, env->P.row_words, env->P.capacity, env->fast_m64, env->P.n_slots, kPol);
 }
 
-// The instantiation that runs.  gfx950 hands out LDS in 1280-byte granules (160 KiB / 128; measured: 8160 B per workgroup gave
-// 18 workgroups per CU, 7648 B gave 20): first fit picks the register budget that matches the replicas the LDS admits; the
-// other policies hold more live state (candidate chunks, scores) and take 128 VGPRs.
-#ifndef ONGYM_POLICY_WAVES      // measured (tools/ab_policies.sh): lowest fragmentation +11 % with 168 registers (its route-score walk
-                                // spills 122 VGPRs at 128), highest SNR -5 % (gather-bound: the fourth wave per SIMD matters more)
-#define ONGYM_POLICY_WAVES (ONGYM_FAST_POLICY == ONGYM_POLICY_LOWEST_FRAGMENTATION ? 3 : 4)
+// Register budget (waves per SIMD) of the non-M64 instantiation that runs.  gfx950 hands out LDS in granules (measured: 8160 B
+// per workgroup gave 18 workgroups per CU, 7648 B gave 20): first fit and load balancing take 5 waves per SIMD (96 VGPRs, a few
+// spills in cold code) when the LDS block admits that many replicas, else 4.  Measured (tools/ab_policies.sh, NSFNET-320,
+// B = 65 536): load balancing +10.5 % at 5 over 4; highest SNR is gather-bound and loses 5 % at 3 (the fourth wave per SIMD
+// matters more than the spills it causes); lowest fragmentation gains 11 % at 3 (its route-score walk spills 122 VGPRs at 4).
+#ifdef ONGYM_POLICY_WAVES
+constexpr int kPolicyWaves = ONGYM_POLICY_WAVES;            // experiment builds
+#else
+constexpr int kPolicyWaves = kPol == ONGYM_POLICY_HIGHEST_SNR ? 4 : kPol == ONGYM_POLICY_LOWEST_FRAGMENTATION ? 3 : 5;
 #endif
 static int waves_of(const ongym_env *env) {
     if (env->fast_m64) return 3;
-    if (kPol != ONGYM_POLICY_FIRST_FIT) return ONGYM_POLICY_WAVES;
+    if (kPolicyWaves != 5) return kPolicyWaves;
     const size_t granule = 1280, per_cu = (160 * 1024) / (((lds_of(env) + granule - 1) / granule) * granule);
     return per_cu >= 17 ? 5 : 4;
 }
@@ -52,9 +55,9 @@ static int with_kernel(const ongym_env *env, bool rec, bool trace, F &&f) {
         return f(k_fast<M64, false, ENT, WAVES, false, kPol>);                                                     \
     }
     ONGYM_TRY_VARIANT(true, 4, 3)
-    if constexpr (kPol == ONGYM_POLICY_FIRST_FIT || ONGYM_POLICY_WAVES == 4) { ONGYM_TRY_VARIANT(false, 2, 4) }
-    if constexpr (kPol != ONGYM_POLICY_FIRST_FIT && ONGYM_POLICY_WAVES == 3) { ONGYM_TRY_VARIANT(false, 2, 3) }
-    if constexpr (kPol == ONGYM_POLICY_FIRST_FIT) { ONGYM_TRY_VARIANT(false, 2, 5) }
+    if constexpr (kPolicyWaves == 3) { ONGYM_TRY_VARIANT(false, 2, 3) }
+    if constexpr (kPolicyWaves >= 4) { ONGYM_TRY_VARIANT(false, 2, 4) }
+    if constexpr (kPolicyWaves == 5) { ONGYM_TRY_VARIANT(false, 2, 5) }
 #undef ONGYM_TRY_VARIANT
     return ONGYM_E_LIMIT;
 }
