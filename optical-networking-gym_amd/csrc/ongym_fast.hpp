@@ -477,20 +477,28 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
     const char __attribute__((address_space(1))) *const tabp = (const char __attribute__((address_space(1))) *)P.pair_tabp;
 
     // LOWEST_FRAGMENTATION: score of a route = 0.33 * mean link entropy + 0.33 * cuts + 0.34 * rss over the route's link rows
-    // (heuristics.py:375-384, utils.pyx:61-107), bit for bit — see lf_route_score (ongym_scored.hpp) for why that is possible;
-    // this is the same walk on 32-bit words.  Lane h walks the OCCUPIED runs of the route's h-th link (the trial allocation
-    // paints free slots free: the score does not depend on the candidate); the entropies are added in the order of path.links.
-    auto route_score = [&](int path, int hops) -> double {
-        double ent = 0.0, sq = 0.0, sl = 0.0;
-        int cuts = 0;
-        if (lane < hops) {
-            const uint32_t *row = occ + (size_t)G(P.path_links)[path * P.max_hops + lane] * RW;
+    // (heuristics.py:375-384, utils.pyx:61-107), bit for bit — see lf_route_score (ongym_scored.hpp) for why that is possible.
+    // The trial allocation paints free slots free, so the score depends on the rows of the route's links only, and a link's
+    // share of it (entropy of its OCCUPIED runs, their number, the sums of their lengths and squared lengths) only changes when
+    // a service is provisioned on or released from that link: lane l keeps link l's four numbers and walks its row again (the
+    // same left-to-right walk on 32-bit words, p*log(p) from the LDS copy of Params.plogp) only when the row changed since —
+    // about five links per request instead of the rows of all k routes.  A route's score then adds the cached entropies in
+    // the order of path.links (ds_bpermute by link index) and the three integer sums over the lanes of its link mask.
+    double ls_ent = 0.0;
+    int ls_cuts = 0, ls_sl = 0, ls_sq = 0;
+    bool ls_dirty = POL == ONGYM_POLICY_LOWEST_FRAGMENTATION && lane < E;
+    auto link_stats_update = [&]() {
+        if (!__ballot(ls_dirty)) return;
+        if (ls_dirty) {
+            double ent = 0.0;
+            int cuts = 0, sl = 0, sq = 0;
+            const uint32_t *row = occ + (size_t)lane * RW;
             int carry = 0;                                   // length of the run that is open at the current position
             auto close = [&](int len) {
-                ent += plt[len];                             // entropy += p * math.log(p) (Params.plogp, copied to LDS)
+                ent += plt[len];                             // entropy += p * math.log(p)
                 cuts++;
-                sq += (double)len * (double)len;
-                sl += (double)len;
+                sq += len * len;
+                sl += len;
             };
             for (int w = 0; w < RW; w++) {
                 const int nb = min(32, S - 32 * w);
@@ -512,14 +520,27 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                 }
             }
             if (carry > 0) close(carry);
-            ent = ent != 0.0 ? -ent : 0.0;                   // utils.pyx:79
+            ls_ent = ent != 0.0 ? -ent : 0.0;                // utils.pyx:79
+            ls_cuts = cuts; ls_sl = sl; ls_sq = sq;
+            ls_dirty = false;
         }
+    };
+    auto bperm_f64 = [&](double v, int src_lane) -> double {       // v of lane src_lane (every lane active)
+        union { double d; int i[2]; } a_, b_;
+        a_.d = v;
+        b_.i[0] = __builtin_amdgcn_ds_bpermute(src_lane << 2, a_.i[0]);
+        b_.i[1] = __builtin_amdgcn_ds_bpermute(src_lane << 2, a_.i[1]);
+        return b_.d;
+    };
+    auto route_score = [&](int path, int hops, uint64_t pmask) -> double {
+        const int lh = lane < hops ? G(P.path_links)[path * P.max_hops + lane] : 0;    // lane h: the route's h-th link
+        const double ent_h = bperm_f64(ls_ent, lh);
         double se = 0.0;                                     // sum(entropies): left to right, starting from int 0
-        for (int h = 0; h < hops; h++) se = __dadd_rn(se, readlane_f64(ent, h));
+        for (int h = 0; h < hops; h++) se = __dadd_rn(se, readlane_f64(ent_h, h));
         se = se / (double)hops;
-        const int tc = wave_sum_i32(cuts);
-        const double tsq = wave_sum(sq), tsl = wave_sum(sl);   // integers < 2^53: exact in any order
-        const double rss = tsl == 0.0 ? 0.0 : sqrt(tsq) / tsl;
+        const bool in = (pmask >> lane) & 1ull;
+        const int tc = wave_sum_i32(in ? ls_cuts : 0), tsl = wave_sum_i32(in ? ls_sl : 0), tsq = wave_sum_i32(in ? ls_sq : 0);
+        const double rss = tsl == 0 ? 0.0 : sqrt((double)tsq) / (double)tsl;
         return uniform_f64(__dadd_rn(__dadd_rn(__dmul_rn(0.33, se), __dmul_rn(0.33, (double)tc)), __dmul_rn(0.34, rss)));
     };
 
@@ -607,9 +628,11 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         }
         if (POL == ONGYM_POLICY_LOWEST_FRAGMENTATION) {
             double v_score = 0.0;
+            link_stats_update();
             for (int k = 0; k < nk; k++) {
-                const double sc = route_score((int)rl((uint32_t)v_path, k), (int)rl(v_hops, k));
-                d_hops += (int)rl(v_hops, k);
+                const PathRec prk = route_rec(k);
+                const double sc = route_score((int)prk.id, (int)prk.hops, mask_of(prk));
+                d_hops += (int)prk.hops;
                 if (lane == k) v_score = sc;
             }
             v_rank = 0;
@@ -952,6 +975,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             // _provision_path (:1288-1325): n slots + one guard slot unless the allocation ends at S
             int end = ch_slot + ch_n; if (end < S) end += 1;
             mark(ch_mask, ch_slot, end, false);
+            if (POL == ONGYM_POLICY_LOWEST_FRAGMENTATION) ls_dirty |= ((ch_mask >> lane) & 1ull) != 0;      // these rows changed
             const float rel = v_at + cur_ht;                  // float + float (:1329); compared as float32 (:1114-1115)
             const uint32_t ra = (uint32_t)ch_mask;
             const uint32_t rb = M64 ? fast_pack_b64(ch_slot, ch_n, ch_m, (uint32_t)(ch_mask >> 32)) : fast_pack_b(ch_slot, ch_n, ch_m, ch_path);
@@ -1092,6 +1116,8 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                     if (M64) mask |= (uint64_t)(__builtin_amdgcn_readfirstlane(ab.y) >> 23) << 32;
                     mark(mask, (int)__builtin_amdgcn_readfirstlane(sk), (int)__builtin_amdgcn_readfirstlane(hi), true);
                 }
+                if (POL == ONGYM_POLICY_LOWEST_FRAGMENTATION)          // the departed service's links: their rows changed
+                    ls_dirty |= lane < 32 ? ((ab.x >> lane) & 1u) != 0 : (M64 && (((ab.y >> 23) >> (lane - 32)) & 1u) != 0);
                 const int last = active - 1;
                 // move the last record into the hole, neutralise the vacated entry
                 const uint2 lab = rec[last];
@@ -1127,6 +1153,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             for (int i = lane; i < active; i += kWave) { rec[i] = make_uint2(0u, 0u); rr[i] = INFINITY; }
             active = 0;
             epp = 0; erej = 0; cnt = 0;
+            if (POL == ONGYM_POLICY_LOWEST_FRAGMENTATION) { ls_ent = 0.0; ls_cuts = ls_sl = ls_sq = 0; ls_dirty = false; }   // empty rows
             if (lane < 5) cold[lane] = 0.0;
             if (lane == 0) ge->svc_list_extra = 0;
             osnr_prod = 1.0;
