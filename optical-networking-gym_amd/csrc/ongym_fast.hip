@@ -55,6 +55,7 @@ static int with_kernel(const ongym_env *env, bool rec, bool trace, F &&f) {
         return f(k_fast<M64, false, ENT, WAVES, false, kPol>);                                                     \
     }
     ONGYM_TRY_VARIANT(true, 4, 3)
+    if constexpr (kPolicyWaves == 2) { ONGYM_TRY_VARIANT(false, 2, 2) }
     if constexpr (kPolicyWaves == 3) { ONGYM_TRY_VARIANT(false, 2, 3) }
     if constexpr (kPolicyWaves >= 4) { ONGYM_TRY_VARIANT(false, 2, 4) }
     if constexpr (kPolicyWaves == 5) { ONGYM_TRY_VARIANT(false, 2, 5) }

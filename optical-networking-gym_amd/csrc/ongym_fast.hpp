@@ -113,6 +113,14 @@ __device__ __forceinline__ double wave_min_f64(double v) {     // as wave_max_f6
     return fmin(fmin(readlane_f64(v, 0), readlane_f64(v, 16)), fmin(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 
+__device__ __forceinline__ float wave_min_f32(float v) {       // wave-uniform result
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)));
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)));
+    return fminf(fminf(rlf(v, 0), rlf(v, 16)), fminf(rlf(v, 32), rlf(v, 48)));
+}
+
 __device__ __forceinline__ int first_set32(uint32_t x) {
     const uint64_t bal = __ballot(x != 0);
     if (!bal) return -1;
@@ -557,6 +565,12 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         return;
     }
 
+    float next_rel;
+    {
+        float m = INFINITY;
+        for (int i = lane; i < active; i += kWave) m = fminf(m, rr[i]);
+        next_rel = wave_min_f32(m);
+    }
     FSTAMP(11);
     for (int it = 0; it < nsteps; ++it) {
         if (TRACE && !have) {           // no request source left: the step is a no-op (as in k_run)
@@ -744,11 +758,14 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                     TabPair t[ENT];
     #pragma unroll
                     for (int e = 0; e < ENT; e++) {
-                        const uint32_t adi = __builtin_amdgcn_sad_u16(e_c2k[e], c2, 0);       // |c2k - c2|, both < 2^11
-                        t[e] = load_pair(tab, e_key4[e] | (adi << 4));
+                        t[e].x = 0.0; t[e].y = 0.0;
+                        if (e == 0 || L > kWave * e) {          // wave-uniform: a cache group without interferers costs nothing
+                            const uint32_t adi = __builtin_amdgcn_sad_u16(e_c2k[e], c2, 0);
+                            t[e] = load_pair(tab, e_key4[e] | (adi << 4));
+                        }
                     }
     #pragma unroll
-                    for (int e = 0; e < ENT; e++) part += t[e].x * e_w1[e] - t[e].y * e_pw2[e];
+                    for (int e = 0; e < ENT; e++) if (e == 0 || L > kWave * e) part = fma(t[e].x, e_w1[e], fma(-t[e].y, e_pw2[e], part));
                 }
                 lane_terms += e_terms;
                 for (int base = kWave * ENT; base < L; base += kWave) {       // interferers beyond the register cache
@@ -820,11 +837,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                 const double c_bw = P.slot_bw * nn, c_h = P.slot_bw * (nn / 2.0);
                 const double c_nlic = readlane_f64(l_nlic, q), c_self = pr.w1 * readlane_f64(l_selfa, q);
                 const double c_lo = readlane_f64(l_lo, q), c_hi = readlane_f64(l_hi, q);
-#ifdef ONGYM_X_REVERSE_PASSES
-                for (int j0 = ((cnt - 1) / (NA * kWave)) * (NA * kWave); j0 >= 0; j0 -= NA * kWave) {
-#else
                 for (int j0 = 0; j0 < cnt; j0 += NA * kWave) {
-#endif
                     const bool two = NA > 1 && j0 + kWave < cnt;          // the second chunk holds candidates (wave-uniform)
                     uint32_t ss[NA], xs[NA];
                     double f[NA], gase[NA];
@@ -977,6 +990,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             mark(ch_mask, ch_slot, end, false);
             if (POL == ONGYM_POLICY_LOWEST_FRAGMENTATION) ls_dirty |= ((ch_mask >> lane) & 1ull) != 0;      // these rows changed
             const float rel = v_at + cur_ht;                  // float + float (:1329); compared as float32 (:1114-1115)
+            next_rel = fminf(next_rel, rel);
             const uint32_t ra = (uint32_t)ch_mask;
             const uint32_t rb = M64 ? fast_pack_b64(ch_slot, ch_n, ch_m, (uint32_t)(ch_mask >> 32)) : fast_pack_b(ch_slot, ch_n, ch_m, ch_path);
             lds_write_lane0(rec_base + (uint32_t)active * 8u, (uint64_t)ra | ((uint64_t)rb << 32), rr_base + (uint32_t)active * 4u, __float_as_uint(rel));
@@ -1131,17 +1145,25 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                 FSTAMP(9);
             }
         };
+        // the earliest release time among the running services is kept between steps: no service leaves before it, and about a
+        // third of the requests arrive before it (departures per inter-arrival time are Poisson with mean ~1): no scan then
+        if (v_at >= next_rel) {
+            float keep_min = INFINITY;
         for (int top = ((active + kWave - 1) / kWave) - 1; top >= 0; top -= 4) {
             const float r0 = rr[top * kWave + lane], r1 = rr[max(top - 1, 0) * kWave + lane];
             const float r2 = rr[max(top - 2, 0) * kWave + lane], r3 = rr[max(top - 3, 0) * kWave + lane];   // unused entries hold +inf
             const uint64_t b0 = __ballot(r0 <= v_at), b1 = top >= 1 ? __ballot(r1 <= v_at) : 0ull;
             const uint64_t b2 = top >= 2 ? __ballot(r2 <= v_at) : 0ull, b3 = top >= 3 ? __ballot(r3 <= v_at) : 0ull;
+            // release times that stay (the moves below do not change the multiset of the remaining ones)
+            keep_min = fminf(fminf(keep_min, r0 <= v_at ? INFINITY : r0), fminf(r1 <= v_at ? INFINITY : r1, fminf(r2 <= v_at ? INFINITY : r2, r3 <= v_at ? INFINITY : r3)));
             FSTAMP(8);
             if (!(b0 | b1 | b2 | b3)) continue;
             depart(top, b0);
             if (b1) depart(top - 1, b1);
             if (b2) depart(top - 2, b2);
             if (b3) depart(top - 3, b3);
+        }
+            next_rel = wave_min_f32(keep_min);
         }
         d_active_sum += (unsigned long long)active;
         const bool terminated = epp == P.episode_length;
@@ -1152,6 +1174,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             for (int i = lane; i < E * RW; i += kWave) occ[i] = word_mask32(i % RW, 0, S);
             for (int i = lane; i < active; i += kWave) { rec[i] = make_uint2(0u, 0u); rr[i] = INFINITY; }
             active = 0;
+            next_rel = INFINITY;
             epp = 0; erej = 0; cnt = 0;
             if (POL == ONGYM_POLICY_LOWEST_FRAGMENTATION) { ls_ent = 0.0; ls_cuts = ls_sl = ls_sq = 0; ls_dirty = false; }   // empty rows
             if (lane < 5) cold[lane] = 0.0;
