@@ -371,7 +371,10 @@ def main():
                                 "per_rank_batch": [int(r[2]) for r in per_rank]}
         if rehearse:
             out["rehearsal"] = "ranks share GPUs, gloo reduction: plumbing check only, not a measurement"
-        out["steady_state"] = bool(counters["mean_active_services"] >= 0.4 * wl["load"])
+        # the timed state must be the loaded network: by Little's law the carried load (offered x accepted fraction) is the mean
+        # number of running services once the network is full; whole episodes from the empty network average ~0.7 of it
+        carried = wl["load"] * (1.0 - out["blocking_rate"])
+        out["steady_state"] = bool(counters["mean_active_services"] >= 0.4 * carried)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(tables, wl, args.workload, args.policy)
         print(json.dumps(out), flush=True)
