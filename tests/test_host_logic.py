@@ -255,6 +255,28 @@ def test_two_rank_gradient_allreduce_gloo(tmp_path):
     assert got["per_rank"][0][1] != got["per_rank"][1][1]       # each rank really had its own gradients before the reduction
 
 
+def test_bench_line_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
+    """bench.py's `issue` / `roofline.traffic` figures come from the tracked counter summary (profiles/pmc_summary.json); every
+    entry carries the hash of the kernel sources it was measured on and bench.py marks an entry of other sources stale."""
+    sys.path.insert(0, REPO)
+    import bench
+    h = bench.kernel_source_hash()
+    assert len(h) == 16 and h == bench.kernel_source_hash()
+    summ = json.load(open(os.path.join(REPO, "profiles", "pmc_summary.json")))
+    for key in ("nsfnet320", "cost239_320", "nobeleu768", "nsfnet320_p1", "nsfnet320_p2", "nsfnet320_p10"):
+        assert "kernel_source_sha" in summ[key] and summ[key]["valu_per_env_step"] > 0, key
+    assert bench.pmc_key("nsfnet320", 0) == "nsfnet320" and bench.pmc_key("nsfnet320", 10) == "nsfnet320_p10"
+    fresh = bench.pmc_summary("nsfnet320", 1)
+    assert fresh["stale"] == (fresh["kernel_source_sha"] != h)
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: "0" * 16)          # any other sources
+    assert bench.pmc_summary("nsfnet320", 1)["stale"] is True
+    assert bench.pmc_summary("no_such_workload") is None
+    # busy fractions: active cycles against the SIMD-clocks one env-step takes at the resident waves per SIMD
+    pm = dict(valu_active_cycles_per_env_step=1000.0, wave_cycles_per_env_step=10000.0)
+    assert bench.busy_frac(pm, "valu_active_cycles_per_env_step", dict(blocks_per_cu=20)) == pytest.approx(0.5)
+    assert bench.busy_frac(pm, "salu_active_cycles_per_env_step", dict(blocks_per_cu=20)) is None
+
+
 # ---- the reference's own unit tests, restated (tests/test_utils.py, tests/test_rmsa.py of the reference) -----------------
 def test_span_link_and_rmsa_plumbing():
     from optical_networking_gym.envs.rmsa import RMSAEnv
