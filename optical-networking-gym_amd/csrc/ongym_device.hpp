@@ -2003,7 +2003,8 @@ __device__ __forceinline__ void policy_highest_snr(Ctx &c, int src, int dst, dou
                 }
                 if (__ballot(fail)) any_osnr = 1;
                 const double vmax = wave_max_f64(v);
-                if (vmax > best_osnr) {                                   // strict: the first maximum wins
+                if (vmax > best_osnr + 1e-9) {                            // strict, beyond the rounding noise (exact ties of the reference: equal routes
+                                                                          // on an empty network; see eval_cands in ongym_fast.hpp): the first maximum wins
                     const uint64_t bal = __ballot(v == vmax);
                     const int ln = __ffsll((unsigned long long)bal) - 1;
                     best_osnr = vmax;

@@ -912,7 +912,10 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                         if (POL == ONGYM_POLICY_HIGHEST_SNR) {
                             const double v = ok ? acc : INFINITY;
                             const double vmin = wave_min_f64(v);
-                            if (vmin < best_acc) {
+                            // a new best must beat the old one by more than the rounding noise between this sum and the
+                            // reference's (different association: ~1e-13): candidates whose 1/GSNR agree to 1e-10 are exact ties
+                            // in the reference (equal routes on an empty network) and the first one keeps the lead there
+                            if (vmin < best_acc * (1.0 - 1e-10)) {
                                 const int ln = __builtin_ctzll(__ballot(v == vmin));
                                 best_acc = vmin; ch_acc = vmin;
                                 ch_k = k; ch_m = m; ch_n = nn; ch_path = path; ch_mask = pmask; ch_slot = (int)rl(ss[a], ln);
@@ -1126,8 +1129,9 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                 if (__builtin_amdgcn_readfirstlane(nk) <= 32u)
                     mark_v(ab.x, M64 ? (ab.y >> 23) : 0u, sk, hi - sk, true);
                 else {
-                    uint64_t mask = __builtin_amdgcn_readfirstlane(ab.x);
-                    if (M64) mask |= (uint64_t)(__builtin_amdgcn_readfirstlane(ab.y) >> 23) << 32;
+                    // (unsigned: readfirstlane returns int, and link 31 / link 40 are the sign bits of the two words)
+                    uint64_t mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)ab.x);
+                    if (M64) mask |= (uint64_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)ab.y) >> 23) << 32;
                     mark(mask, (int)__builtin_amdgcn_readfirstlane(sk), (int)__builtin_amdgcn_readfirstlane(hi), true);
                 }
                 if (POL == ONGYM_POLICY_LOWEST_FRAGMENTATION)          // the departed service's links: their rows changed

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Soak: 1 024 replicas x 8 000 steps (eight episodes) per topology with launch power -8..+8 dBm, load 100..1000 Erlang and
-margins 0..3 dB spread over the replicas; every replica's final grid, clocks and counters against the CPU oracle
-(OpenMP over replicas, ~1 min).  Last run (round 2, lean kernel, profiles/r02_soak_vs_oracle.txt): 0 differing replicas of 1 024 on NSFNET and on COST239,
-i.e. 16.4 M requests without one differing accept / slot decision.   python tools/soak_vs_oracle.py   (repository root, GPU)"""
+"""Soak: many replicas x thousands of steps (several episodes) per case with launch power -8..+8 dBm, load 100..1000 Erlang and
+margins 0..3 dB spread over the replicas; every replica's final grid, clocks and counters against the CPU oracle (OpenMP over
+replicas).  Cases: first fit on NSFNET / COST239 / nobel-eu, and the lean kernels of load balancing, highest SNR and lowest
+fragmentation.  Last run: profiles/r03_soak_vs_oracle.txt.   python tools/soak_vs_oracle.py [case indices]   (repository root, GPU)"""
 import sys, os, time
 sys.path[:0] = ["tests", "optical-networking-gym_amd"]
 import numpy as np
@@ -10,10 +10,18 @@ from common import golden_tables, jocn_modulations
 from oracle_lib import OracleEnv, batch_run_first_fit
 from optical_networking_gym import _native as nat
 from optical_networking_gym.envs.batched import BatchedQRMSAEnv
-B, steps = 1024, 8000
+from oracle_lib import batch_run_policy
 rng = np.random.default_rng(7)
-loads = rng.uniform(100, 1000, B); lps = rng.uniform(-8.0, 8.0, B); margins = rng.choice([0.0, 0.5, 1.5, 3.0], B)
-for topo, S in (("nsfnet", 320), ("cost239", 320)):
+# (topology, slots, policy id, replicas, steps): first fit on three topologies (nobel-eu: the M64 record codec), then the lean
+# kernels of the other three JOCN heuristics (the oracle's highest SNR / lowest fragmentation run at tens of steps per second
+# per core: smaller samples)
+CASES = [("nsfnet", 320, 0, 1024, 8000), ("cost239", 320, 0, 1024, 8000), ("nobel-eu", 320, 0, 1024, 4000),
+         ("nsfnet", 320, 1, 1024, 4000), ("nsfnet", 160, 2, 128, 1500), ("nsfnet", 160, 10, 128, 1500)]
+if len(sys.argv) > 1:
+    CASES = [CASES[int(a)] for a in sys.argv[1:]]
+threads = len(os.sched_getaffinity(0))
+for topo, S, pid, B, steps in CASES:
+    loads = rng.uniform(100, 1000, B) * S / 320; lps = rng.uniform(-8.0, 8.0, B); margins = rng.choice([0.0, 0.5, 1.5, 3.0], B)
     kw = dict(modulations=jocn_modulations(), num_spectrum_resources=S, batch=B, capacity=1024, episode_length=1000,
               auto_reset=True, load=300, bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400, 1000),
               replica_load=loads, replica_launch_power_dbm=lps, replica_margin=margins)
@@ -23,17 +31,23 @@ for topo, S in (("nsfnet", 320), ("cost239", 320)):
                           bit_rates=(10, 40, 100, 400, 1000), replica_load=loads, replica_launch_power_dbm=lps,
                           replica_margin=margins)
     env.seed(2025); env.reset()
-    for _ in range(steps // 1000): env.step_policy(1000, record=False)
+    assert env.occupancy(pid)["lean_kernel"]
+    done = 0
+    while done < steps:
+        n = min(500, steps - done)
+        env.step_policy(n, record=False, policy=pid); done += n
     st = env.stats()
     t0 = time.time()
     oracles = []
     for r in range(B):
         o = OracleEnv(holder, replica=r); o.seed(2025); o.reset(); oracles.append(o)
-    assert batch_run_first_fit(oracles, steps, 16) == B * steps
+    assert batch_run_policy(oracles, pid, steps, threads) == B * steps
     bad = 0
     for r, o in enumerate(oracles):
         so = o.stats()
         ok = all(st[r][f] == so[f] for f in ("services_accepted", "bit_rate_provisioned", "current_time", "active", "rejected",
-                                             "last_episode_accepted", "total_paths_tried")) and np.array_equal(env.grid(r), o.grid())
+                                             "last_episode_accepted", "total_paths_tried" if pid == 0 else "episode_services_accepted")) \
+            and np.array_equal(env.grid(r), o.grid())
         bad += (not ok)
-    print(topo, "replicas differing:", bad, "of", B, "| oracle time %.1f s" % (time.time() - t0), flush=True)
+    print(f"{topo} S={S} policy {pid}: replicas differing: {bad} of {B} after {steps} steps each ({B * steps / 1e6:.1f} M requests) | "
+          f"oracle time {time.time() - t0:.1f} s on {threads} threads", flush=True)
