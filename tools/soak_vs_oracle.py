@@ -16,7 +16,10 @@ rng = np.random.default_rng(7)
 # kernels of the other three JOCN heuristics (the oracle's highest SNR / lowest fragmentation run at tens of steps per second
 # per core: smaller samples)
 CASES = [("nsfnet", 320, 0, 1024, 8000), ("cost239", 320, 0, 1024, 8000), ("nobel-eu", 320, 0, 1024, 4000),
-         ("nsfnet", 320, 1, 1024, 4000), ("nsfnet", 160, 2, 128, 1500), ("nsfnet", 160, 10, 128, 1500)]
+         ("nsfnet", 320, 1, 1024, 4000), ("nsfnet", 160, 2, 128, 1500), ("nsfnet", 160, 10, 128, 1500),
+         # the M64 instantiations of the policy kernels (41 links) and COST239
+         ("nobel-eu", 320, 1, 512, 3000), ("nobel-eu", 160, 2, 96, 1200), ("nobel-eu", 160, 10, 96, 1200),
+         ("cost239", 160, 2, 96, 1200), ("cost239", 160, 10, 96, 1200)]
 if len(sys.argv) > 1:
     CASES = [CASES[int(a)] for a in sys.argv[1:]]
 threads = len(os.sched_getaffinity(0))
