@@ -175,6 +175,34 @@ def test_observation_randomised_configurations_vs_oracle(case):
         np.testing.assert_allclose(obs[r], want_obs, rtol=2e-6, atol=2e-7, err_msg=f"case {case}: obs replica {r}")
 
 
+@pytest.mark.parametrize("topo,S", [("nsfnet", 320), ("nobel-eu", 320), ("cost239", 200)])
+def test_observation_wide_services_vs_oracle(topo, S):
+    """Observation + mask with 1 Tb/s requests (up to 80 slots: more than one bitmap word) among the running services and as
+    the current request, launch powers and margins spread over the replicas, on three topologies (nobel-eu: 41 links, the
+    generic record codec): against the oracle after a first-fit warm-up."""
+    B, warm = 10, 520
+    rng = np.random.default_rng(17)
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=S, capacity=1024, load=300, bit_rate_selection="discrete",
+              bit_rates=(10, 40, 100, 400, 1000), auto_reset=True, episode_length=1000,
+              replica_load=rng.uniform(150, 700, B) * S / 320, replica_launch_power_dbm=rng.uniform(-5.0, 5.0, B),
+              replica_margin=rng.choice([0.0, 0.5, 1.5], B))
+    holder = nat.ConfigHolder(golden_tables(topo), batch=B, **kw)
+    env = BatchedQRMSAEnv(tables=golden_tables(topo), batch_size=B, **kw)
+    env.seed(23); env.reset()
+    env.step_policy(warm, record=False)
+    obs, mask = env.observe()
+    pl = np.ctypeslib.as_array(holder.struct.path_len_norm, shape=(holder.struct.n_paths,))
+    wide = 0
+    for r in range(B):
+        o = OracleEnv(holder, replica=r)
+        o.seed(23); o.reset(); o.run_first_fit(warm)
+        wide += int((o.services()["nslots"] > 32).sum())
+        want_obs, want_mask = o.observe(pl, holder.struct.max_bit_rate)
+        np.testing.assert_array_equal(mask[r], want_mask, err_msg=f"{topo}: mask replica {r}")
+        np.testing.assert_allclose(obs[r], want_obs, rtol=2e-6, atol=2e-7, err_msg=f"{topo}: obs replica {r}")
+    assert wide > 0
+
+
 def test_observation_continuous_bit_rates_vs_oracle():
     """bit_rate_selection="continuous" (randint bit rates, slot counts by ceil): the observation normalises the bit rate by
     max(bit_rates) of the otherwise unused tuple (qrmsa.pyx:679, 688); device vs oracle on loaded states."""

@@ -1354,3 +1354,27 @@ def test_highest_snr_exact_ties_between_equal_routes(generic, monkeypatch):
         for f in ("services_accepted", "episode_services_accepted", "rejected", "bit_rate_provisioned", "active", "current_time"):
             assert st[r][f] == so[f], (r, f)
         np.testing.assert_array_equal(env.grid(r), o.grid())
+
+
+@pytest.mark.parametrize("pid", list(range(2, 11)))
+def test_policies_wide_services_41_links_vs_oracle(pid):
+    """Every fused policy but full MSCL on nobel-eu (41 links) with 1 Tb/s requests (up to 80 slots) in the mix, after a
+    first-fit warm-up that has provisioned and released wide services: records and grids against the oracle."""
+    tb = golden_tables("nobel-eu")
+    B, warm = 4, 600
+    steps = 60 if pid in (2, 10) else 220
+    rng = np.random.default_rng(40 + pid)
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=200, capacity=1024, episode_length=1000, auto_reset=True,
+              load=300, bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400, 1000),
+              replica_load=rng.uniform(100, 450, B), replica_launch_power_dbm=rng.uniform(-3.0, 4.0, B),
+              replica_margin=rng.choice([0.0, 0.5], B))
+    holder = nat.ConfigHolder(tb, batch=B, **kw)
+    env = BatchedQRMSAEnv(tables=tb, batch_size=B, **kw)
+    env.seed(77); env.reset()
+    env.step_policy(warm, record=False)
+    got = env.step_policy(steps, policy=pid)
+    for r in range(B):
+        o = OracleEnv(holder, replica=r)
+        o.seed(77); o.reset(); o.run_policy(0, warm)
+        assert_records_equal(got[:, r], o.run_policy(pid, steps), f"policy {pid} replica {r}")
+        np.testing.assert_array_equal(env.grid(r), o.grid())
