@@ -39,6 +39,7 @@
 namespace ongym {
 
 constexpr int kTabPitch = 2048;      // pair-table row pitch (2S+1 <= 2047)
+constexpr int kNearHalfSlots = 32;   // candidate-lane evaluation: interferers this close to the pass's candidates are staged first
 
 // ---- path record (8 dwords, 32-byte aligned: one s_load_dwordx8) -------------------------------------------------------
 struct PathRec {
@@ -853,6 +854,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                         gase[a] = (c_bw * fc * pr.ase) * rp0;
                     }
                     const double thr = POL == ONGYM_POLICY_HIGHEST_SNR ? fmin(c_hi, best_acc) : c_hi;
+                    const int x_lo = 2 * (int)xlist[j0] + nn, x_hi = 2 * (int)xlist[min(j0 + NA * kWave, cnt) - 1] + nn;     // span of the pass's centres
                     bool cut = false;
                     for (int base = 0; base < L && !cut; base += kWave) {
                         {   // stage: lane j = interferer base + j (zero weights beyond the list)
@@ -860,8 +862,16 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                             double w1 = 0.0, pw2 = 0.0;
                             if (base + lane < L) intf_of((int)list[base + lane], pr.mask_lo, pr.mask_hi, c2k, key4, w1, pw2);
                             key4 |= ((c2k + (uint32_t)nn) & 1u) << 14;       // the parity half of the row: every candidate of the pass has x = 2s + nn
-                            st_ck[lane] = make_uint2(c2k, key4);
-                            st_w[lane] = make_double2(w1, pw2);
+                            // interferers within kNearHalfSlots half slots of the pass's candidates first (stable partition): their terms
+                            // are the large ones, so the partial sums reach the threshold sooner (+7 % with the exit test every four
+                            // interferers; the window size hardly matters: 8..96 half slots give +6.4..+7.7 %)
+                            const bool real_ = base + lane < L;
+                            const bool near_ = real_ && (int)c2k >= x_lo - kNearHalfSlots && (int)c2k <= x_hi + kNearHalfSlots;
+                            const uint64_t bn = __ballot(near_);
+                            const int pn = __builtin_amdgcn_mbcnt_hi((uint32_t)(bn >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bn, 0));
+                            const int pos = near_ ? pn : __popcll((unsigned long long)bn) + (lane - pn);
+                            st_ck[pos] = make_uint2(c2k, key4);
+                            st_w[pos] = make_double2(w1, pw2);
                         }
                         wave_sync();
                         const int ne = min(kWave, L - base);
