@@ -97,6 +97,16 @@ __device__ __forceinline__ uint32_t next_word32(uint32_t x) {
 
 // run-AND on 32-bit words (see run_and): bit s of word w set iff slots [32w+s, 32w+s+m) are all free
 __device__ __forceinline__ uint32_t run_and32(uint32_t x, int &r, int m) {
+#ifndef ONGYM_X_RUNAND_GENERAL
+    if (m <= 63) {                                   // every shift min(r, m - r) is in 1..31: one DPP + v_alignbit + v_and per step
+        while (r < m) {
+            const int s = min(r, m - r);
+            x &= __builtin_amdgcn_alignbit(next_word32(x), x, s);
+            r += s;
+        }
+        return x;
+    }
+#endif
     while (r < m) {
         const int s = min(r, m - r);
         uint32_t y = x;
@@ -112,6 +122,43 @@ __device__ __forceinline__ uint32_t run_and32(uint32_t x, int &r, int m) {
 __device__ __forceinline__ double wave_min_f64(double v) {     // as wave_max_f64 (ongym_device.hpp); wave-uniform result
     v = fmin(v, dpp_f64<0xB1>(v)); v = fmin(v, dpp_f64<0x4E>(v)); v = fmin(v, dpp_f64<0x141>(v)); v = fmin(v, dpp_f64<0x140>(v));
     return fmin(fmin(readlane_f64(v, 0), readlane_f64(v, 16)), fmin(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
+
+// Wave-wide fp64 sum for eval_one (every lane ends up with a usable copy of the total).
+//   default            : 4 symmetric DPP exchanges inside the rows of 16 lanes, then the rows combined with DPP row_bcast:15 /
+//                        row_bcast:31 (total in lane 63, one v_readlane pair): 22 vector instructions, +1.7 % (first fit) over
+//   ONGYM_X_ROW_SUM    : wave_sum (ongym_device.hpp): the 4 row sums through 8 v_readlane + 3 adds (31 vector instructions)
+//   ONGYM_X_MFMA_SUM   : two v_mfma_f64_16x16x4_f64 against a matrix of ones + three adds (5 issue slots instead of 31).
+//                        Measured on MI355X in round 3: 0.89x (first fit) - an fp64 16x16x4 MFMA occupies the matrix pipe for
+//                        64 clocks on gfx950 (fp64 matrix rate = vector rate), two dependent ones cost more than the 31 VALU.
+typedef double double4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double wave_sum_eval(double v) {
+#if defined(ONGYM_X_MFMA_SUM)
+    // A[i][k] = lane 16k + i, B = 1: D[i][j] = sum of lanes {i, i+16, i+32, i+48}; a lane's four accumulators hold four different
+    // rows i and the four 16-lane groups hold all sixteen, so s = d0+d1+d2+d3 per group, and a second MFMA adds the four groups
+    const double4_t z = {0.0, 0.0, 0.0, 0.0};
+    const double4_t d = __builtin_amdgcn_mfma_f64_16x16x4f64(v, 1.0, z, 0, 0, 0);
+    const double s = (d[0] + d[1]) + (d[2] + d[3]);
+    const double4_t t = __builtin_amdgcn_mfma_f64_16x16x4f64(s, 1.0, z, 0, 0, 0);
+    return t[0];
+#elif !defined(ONGYM_X_ROW_SUM)
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    v += dpp_f64<0x140>(v);                 // every lane of a row holds the row's sum
+    union { double d; int i[2]; } a, b;
+    a.d = v;                                // rows 1 and 3 += lane 15 of the row before (row_bcast:15, row_mask 0b1010)
+    b.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x142, 0xA, 0xF, false);
+    b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x142, 0xA, 0xF, false);
+    v += b.d;
+    a.d = v;                                // rows 2 and 3 += lane 31 (row_bcast:31, row_mask 0b1100): row 3 holds the total
+    b.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x143, 0xC, 0xF, false);
+    b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x143, 0xC, 0xF, false);
+    v += b.d;
+    return readlane_f64(v, 63);
+#else
+    return wave_sum(v);
+#endif
 }
 
 __device__ __forceinline__ float wave_min_f32(float v) {       // wave-uniform result
@@ -335,6 +382,21 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
     const int &w_n = kLF ? t1_n : t_n;
     const double &w_nlic = kLF ? t1_nlic : t_nlic, &w_selfa = kLF ? t1_selfa : t_selfa;
     const double &w_lim_lo = kLF ? t1_lim_lo : t_lim_lo, &w_lim_hi = kLF ? t1_lim_hi : t_lim_hi;
+    // 1/GSNR of a candidate (start s) on a route is  (w_c1 + w_cb * s) * path_ase  +  w_nlic * (interferer sum)  +  w_c2 * path_w1
+    // for the lane's (bit rate, format): the launch-invariant factors are kept per lane, so that a route costs three multiplications
+    // (lane_fac) and an evaluation two FMAs after its sum.  w_c1 and w_c2 are computed in the order the bound always used; the
+    // ASE term of an evaluation is now associated as (bw (f0 + h)/P + bw slot_bw/P * s) * ase instead of (bw (f0 + slot_bw s + h) ase)/P
+    // (envs/qrmsa.pyx:901-905): a difference of a few ulp, far inside qot_ok's 1e-9 band and the 1e-9 the statistics are held to.
+    struct LaneFac { double c1, cb, c2; };
+    auto lane_fac = [&](int n_, double nlic_, double selfa_) -> LaneFac {
+        const double bw = P.slot_bw * n_, h = P.slot_bw * (n_ / 2.0);
+        LaneFac f;
+        f.c1 = (bw * (P.f0 + h)) * rp0;
+        f.cb = (bw * P.slot_bw) * rp0;
+        f.c2 = nlic_ * selfa_;
+        return f;
+    };
+    const LaneFac w_fac = lane_fac(w_n, w_nlic, w_selfa);
 
     // ---- wave-uniform state from DevEnv ----
     uint64_t req_base = readlane_u64(ge->req_index, 0);        // ring lane i = request req_base + i
@@ -351,14 +413,16 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
     int lane_terms = 0;
     // current request (drawn by whoever ran before: k_reset, k_run or a previous k_fast launch)
     float cur_ht = uniform_f32(ge->cur_ht);
-    int cur_src = uniform_i32(ge->cur_src), cur_dst = uniform_i32(ge->cur_dst);
+    // source | destination << 6, unpacked where a route beyond the first is looked up (9 % of the requests with first fit)
+    uint32_t cur_sd = (uint32_t)uniform_i32(ge->cur_src) | ((uint32_t)uniform_i32(ge->cur_dst) << 6);
+    auto pair_base = [&]() -> int { return ((int)(cur_sd & 63u) * N + (int)(cur_sd >> 6)) * K; };      // index of the pair's first route
     int cur_bi;
     {
         const float br = uniform_f32(ge->cur_br);
         const uint64_t hit = __ballot(lane < P.n_bit_rates && (float)G(P.bit_rates)[min(lane, P.n_bit_rates - 1)] == br);
         cur_bi = hit ? __builtin_ctzll(hit) : 0;
     }
-    int cur_p0 = uniform_i32(KC(P.pair_paths)[(cur_src * N + cur_dst) * K]);
+    int cur_p0 = uniform_i32(KC(P.pair_paths)[pair_base()]);
     const __attribute__((address_space(4))) PathRec *const path_recs = KC(reinterpret_cast<const PathRec *>(P.path_rec));
     // launch deltas
     int d_pops = 0, d_acc = 0, d_steps = 0, d_evals = 0, d_skips = 0, d_paths = 0, d_hops = 0, d_flags = 0, d_episodes = 0;
@@ -390,7 +454,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             ongym_stats &s = ge->st;
             ge->req_index = req_base + (uint64_t)rq_pos;
             s.current_time = (double)v_at;
-            ge->cur_at = v_at; ge->cur_ht = cur_ht; ge->cur_br = brs[cur_bi]; ge->cur_src = cur_src; ge->cur_dst = cur_dst;
+            ge->cur_at = v_at; ge->cur_ht = cur_ht; ge->cur_br = brs[cur_bi]; ge->cur_src = (int)(cur_sd & 63u); ge->cur_dst = (int)(cur_sd >> 6);
             ge->cur_id = epp - 1; ge->have_request = have ? 1 : 0;
             s.services_processed += d_pops; s.episode_services_processed = epp;
             s.services_accepted += d_acc; s.total_accepted += d_acc;
@@ -425,7 +489,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         else v_at = v_at + rlf(rq_iat, rq_pos);         // at = float32(current_time + expovariate)
         cur_ht = rlf(rq_ht, rq_pos);
         rq_pos++;
-        cur_src = pk & 63; cur_dst = (pk >> 6) & 63; cur_bi = (pk >> 12) & 7; cur_p0 = (int)(pk >> 15) - 1;
+        cur_sd = pk & 0xFFFu; cur_bi = (pk >> 12) & 7; cur_p0 = (int)(pk >> 15) - 1;
         epp++; d_pops++;
         cnt += (lane == 16 + cur_bi) ? 1 : 0;           // bit_rate_requested, by bit rate
     };
@@ -602,7 +666,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         double v_ase = 0.0, v_w1 = 0.0;
         if (POL != ONGYM_POLICY_FIRST_FIT) {
             if (lane < K) {
-                v_path = G(P.pair_paths)[(cur_src * N + cur_dst) * K + lane];
+                v_path = G(P.pair_paths)[pair_base() + lane];
                 if (v_path >= 0) {
                     const auto *g = G(reinterpret_cast<const PathRec *>(P.path_rec)) + v_path;
                     v_hops = g->hops; v_mlo = g->mask_lo; v_mhi = g->mask_hi; v_ase = g->ase; v_w1 = g->w1;
@@ -662,7 +726,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             int k = r, path;
             PathRec pr;
             if (POL == ONGYM_POLICY_FIRST_FIT) {
-                path = k == 0 ? cur_p0 : uniform_i32(KC(P.pair_paths)[(cur_src * N + cur_dst) * K + k]);
+                path = k == 0 ? cur_p0 : uniform_i32(KC(P.pair_paths)[pair_base() + k]);
                 if (path < 0) break;
                 // (fetching the first route's record already when the request is popped was measured 2.4 % SLOWER: eight more
                 //  live SGPRs across the departures scan cost more than the scalar-load latency they hide)
@@ -677,8 +741,8 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             // modulations whose lower bound at slot 0 already fails cannot pass at any slot
             // lower bound of 1/GSNR at slot 0 = ASE(slot 0) + self-channel NLI (a few fp64 operations per lane: cheaper than
             // keeping their factors in registers for the whole launch)
-            const double t_bw = P.slot_bw * w_n, t_h = P.slot_bw * (w_n / 2.0);
-            const double lb = ((t_bw * (P.f0 + t_h)) * rp0) * pr.ase + (w_nlic * w_selfa) * pr.w1;
+            const double r_a = w_fac.c1 * pr.ase, r_b = w_fac.cb * pr.ase, r_d = w_fac.c2 * pr.w1;    // this route's ASE at slot 0, ASE per slot, self-channel NLI
+            const double lb = r_a + r_d;
             // (lb >= lim*(1+1e-9) => the full sum is at least that large up to rounding, and inside the 1e-9 band the
             //  dB-domain test rejects anything above lim: the skipped evaluation would have failed)
             uint32_t feas = (uint32_t)(__ballot(lb < w_lim_hi) >> (8 * cur_bi)) & 0xFFu;
@@ -751,7 +815,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             // pass 2: 1/GSNR of ONE candidate (start `first`, width nn) with lanes over the interferers.  Every lane finishes the
             // evaluation for ITS (bit rate, format) entry of the per-lane tables l_*; lane q is the one that counts.  Returns
             // the decision of qot_ok; ev_acc (and ev_ase / ev_nli when records are written) hold lane q's values when it passes.
-            auto eval_one = [&](int first, int nn, int q, const PathRec &pr, double l_bw, double l_h, double l_nlic, double l_selfa,
+            auto eval_one = [&](int first, int nn, int q, const PathRec &pr, double l_a, double l_b, double l_d, double l_nlic,
                                 double l_lo, double l_hi) -> int {
                 const uint32_t c2 = (uint32_t)(2 * first + nn);
                 double part = 0.0;
@@ -765,8 +829,8 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                             t[e] = load_pair(tab, e_key4[e] | (adi << 4));
                         }
                     }
-    #pragma unroll
-                    for (int e = 0; e < ENT; e++) if (e == 0 || L > kWave * e) part = fma(t[e].x, e_w1[e], fma(-t[e].y, e_pw2[e], part));
+    #pragma unroll              // (a group without interferers has zero weights and zero table values: no select needed)
+                    for (int e = 0; e < ENT; e++) part = fma(t[e].x, e_w1[e], fma(-t[e].y, e_pw2[e], part));
                 }
                 lane_terms += e_terms;
                 for (int base = kWave * ENT; base < L; base += kWave) {       // interferers beyond the register cache
@@ -781,10 +845,9 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                     }
                 }
                 d_evals++;
-                const double tot = wave_sum(part);
-                const double fc = P.f0 + (P.slot_bw * first) + l_h;                  // envs/qrmsa.pyx:901-905
-                const double g_nli = l_nlic * (tot + pr.w1 * l_selfa);
-                const double g_ase = (l_bw * fc * pr.ase) * rp0;
+                const double tot = wave_sum_eval(part);
+                const double g_nli = fma(l_nlic, tot, l_d);
+                const double g_ase = fma(l_b, (double)first, l_a);                  // envs/qrmsa.pyx:901-905, see lane_fac
                 const double acc = g_ase + g_nli;
                 int ok;
                 {
@@ -962,7 +1025,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                     FSTAMP(15);
                     continue;
                 }
-                const int ok = eval_one(first, nn, q, pr, t_bw, t_h, w_nlic, w_selfa, w_lim_lo, w_lim_hi);
+                const int ok = eval_one(first, nn, q, pr, r_a, r_b, r_d, w_nlic, w_lim_lo, w_lim_hi);
                 FSTAMP(5);
                 if (ok) {
                     ch_k = k; ch_m = m; ch_slot = first; ch_n = n; ch_path = path;
@@ -984,8 +1047,8 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                 // `env.step(action)` evaluates the GN model itself at the width the format needs (the heuristic asked for one slot
                 // more): the reference raises ValueError if that fails (envs/qrmsa.pyx:925-929) — a fused episode rejects the
                 // request and flags it (as k_run does).  Same route: the interferer cache is the one just used.
-                const double s_bw = P.slot_bw * t_n, s_h = P.slot_bw * (t_n / 2.0);
-                if (eval_one(ch_slot, ch_n, 8 * cur_bi + ch_m, pr, s_bw, s_h, t_nlic, t_selfa, t_lim_lo, t_lim_hi)) {
+                const LaneFac sf = lane_fac(t_n, t_nlic, t_selfa);
+                if (eval_one(ch_slot, ch_n, 8 * cur_bi + ch_m, pr, sf.c1 * pr.ase, sf.cb * pr.ase, sf.c2 * pr.w1, t_nlic, t_lim_lo, t_lim_hi)) {
                     ch_acc = ev_acc; ch_ase = ev_ase; ch_nli = ev_nli;
                 } else { ch_k = -1; lf_qot = true; }
                 break;
@@ -1030,7 +1093,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                 if (POL == ONGYM_POLICY_LOWEST_FRAGMENTATION) n_small += 1;
                 int bosnr = 0;
                 for (int k = 0; k < K && !bosnr && n_small <= S; k++) {
-                    const int path = uniform_i32(KC(P.pair_paths)[(cur_src * N + cur_dst) * K + k]);
+                    const int path = uniform_i32(KC(P.pair_paths)[pair_base() + k]);
                     if (path < 0) break;
                     const PathRec pr = load_path_rec(path_recs, path);
                     const uint32_t x = path_and(M64 ? ((uint64_t)pr.mask_lo | ((uint64_t)(pr.mask_hi & 0x1FFu) << 32)) : (uint64_t)pr.mask_lo);
@@ -1051,7 +1114,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                     n_small = min(n_small, n); n_big = max(n_big, n); n_last = n;
                 }
                 for (int k = 0; k < K && n_big > 0; k++) {
-                    const int path = uniform_i32(KC(P.pair_paths)[(cur_src * N + cur_dst) * K + k]);
+                    const int path = uniform_i32(KC(P.pair_paths)[pair_base() + k]);
                     if (path < 0) break;
                     const PathRec pr = load_path_rec(path_recs, path);
                     const uint32_t x = path_and(M64 ? ((uint64_t)pr.mask_lo | ((uint64_t)(pr.mask_hi & 0x1FFu) << 32)) : (uint64_t)pr.mask_lo);
