@@ -354,7 +354,7 @@ def main():
                                           "tracked PMC passes x env-steps per launch; state is LDS-resident for a whole "
                                           "launch, so real traffic is far BELOW the algorithmic bytes and the HBM bound "
                                           "does not bind: see `issue`") if traffic is not None else None,
-                         "kernel": (f"k_fast<M64,REC,ENT,WAVES,TRACE,POL={args.policy}> (csrc/ongym_fast.hpp)" if occ["lean_kernel"]
+                         "kernel": (f"k_fast<M64,REC,ENT,WAVES,TRACE,POL={args.policy},WIDE> (csrc/ongym_fast.hpp)" if occ["lean_kernel"]
                                     else "k_run<uniform_alpha,codec,waves,policy> (csrc/ongym_device.hpp)"),
                          "avg_launch_ms": avg_launch_s * 1e3,
                          "algorithmic_bytes_per_env_step": bytes_step, "env_steps_per_launch": env_steps_per_launch,

@@ -1,5 +1,6 @@
-// ongym_fast.hip — the lean fused policy+step kernels (ongym_fast.hpp), one translation unit per policy:
-//   hipcc -c -DONGYM_FAST_POLICY=<ONGYM_POLICY_* id> ongym_fast.hip -o ongym_fast_p<id>.o
+// ongym_fast.hip — the lean fused policy+step kernels (ongym_fast.hpp), two translation units per policy:
+//   hipcc -c -DONGYM_FAST_POLICY=<ONGYM_POLICY_* id> -DONGYM_FAST_WIDE=<0|1> ongym_fast.hip -o ongym_fast_p<id>[w].o
+// (WIDE = 0: every slot count of the configuration is <= 32, see ongym_env::fast_wide)
 // (the units compile in parallel; see __graft_entry__.build).  Each exports fast_launch / fast_occupancy / fast_prepare
 // for its policy; ongym_hip.hip dispatches on the policy id.
 #include <hip/hip_runtime.h>
@@ -17,10 +18,15 @@ constexpr int kPol = ONGYM_FAST_POLICY;
 
 // M64: link masks need two words (32 < n_links <= 52); ENT: interferers per lane cached in registers; WAVES: waves per
 // SIMD the register allocation is bounded for; POL: the policy (part of the kernel's name: one set of kernels per unit)
-template <bool M64, bool REC, int ENT, int WAVES, bool TRACE, int POL>
+#ifndef ONGYM_FAST_WIDE
+#define ONGYM_FAST_WIDE 1
+#endif
+constexpr bool kWide = ONGYM_FAST_WIDE != 0;
+// (WIDE is part of the kernel's name: the narrow and the wide unit of a policy are linked into one library)
+template <bool M64, bool REC, int ENT, int WAVES, bool TRACE, int POL, bool WIDE>
 __global__ __launch_bounds__(64, WAVES) void k_fast(const Params *__restrict__ Pp, int nsteps, ongym_step_rec *out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    fast_run<M64, REC, ENT, TRACE, POL>(*Pp, nsteps, out, smem);
+    fast_run<M64, REC, ENT, TRACE, POL, WIDE>(*Pp, nsteps, out, smem);
 }
 
 static size_t lds_of(const ongym_env *env) {
@@ -49,10 +55,10 @@ static int with_kernel(const ongym_env *env, bool rec, bool trace, F &&f) {
     const int waves = waves_of(env);
 #define ONGYM_TRY_VARIANT(M64, ENT, WAVES)                                                                         \
     if (env->fast_m64 == M64 && waves == WAVES) {                                                                  \
-        if (trace && rec) return f(k_fast<M64, true, ENT, WAVES, true, kPol>);                                     \
-        if (trace) return f(k_fast<M64, false, ENT, WAVES, true, kPol>);                                           \
-        if (rec) return f(k_fast<M64, true, ENT, WAVES, false, kPol>);                                             \
-        return f(k_fast<M64, false, ENT, WAVES, false, kPol>);                                                     \
+        if (trace && rec) return f(k_fast<M64, true, ENT, WAVES, true, kPol, kWide>);                                     \
+        if (trace) return f(k_fast<M64, false, ENT, WAVES, true, kPol, kWide>);                                           \
+        if (rec) return f(k_fast<M64, true, ENT, WAVES, false, kPol, kWide>);                                             \
+        return f(k_fast<M64, false, ENT, WAVES, false, kPol, kWide>);                                                     \
     }
     ONGYM_TRY_VARIANT(true, 4, 3)
     if constexpr (kPolicyWaves == 2) { ONGYM_TRY_VARIANT(false, 2, 2) }
@@ -65,7 +71,11 @@ static int with_kernel(const ongym_env *env, bool rec, bool trace, F &&f) {
 
 #define FAST_CAT2(a, b) a##b
 #define FAST_CAT(a, b) FAST_CAT2(a, b)
+#if ONGYM_FAST_WIDE
+#define FAST_FN(name) FAST_CAT(FAST_CAT(name##_p, ONGYM_FAST_POLICY), w)
+#else
 #define FAST_FN(name) FAST_CAT(name##_p, ONGYM_FAST_POLICY)
+#endif
 
 int FAST_FN(fast_prepare)(ongym_env *env) {
     const size_t lds = lds_of(env);

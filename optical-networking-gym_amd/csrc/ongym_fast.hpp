@@ -95,10 +95,12 @@ __device__ __forceinline__ uint32_t next_word32(uint32_t x) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xF, 0xF, true);
 }
 
-// run-AND on 32-bit words (see run_and): bit s of word w set iff slots [32w+s, 32w+s+m) are all free
+// run-AND on 32-bit words (see run_and): bit s of word w set iff slots [32w+s, 32w+s+m) are all free.  WIDE = false: the caller
+// guarantees m <= 63 (every slot count of the configuration is <= 32), so every shift min(r, m - r) is in 1..31: one DPP move +
+// v_alignbit + v_and and four scalar instructions per step.
+template <bool WIDE>
 __device__ __forceinline__ uint32_t run_and32(uint32_t x, int &r, int m) {
-#ifndef ONGYM_X_RUNAND_GENERAL
-    if (m <= 63) {                                   // every shift min(r, m - r) is in 1..31: one DPP + v_alignbit + v_and per step
+    if (!WIDE || m <= 63) {
         while (r < m) {
             const int s = min(r, m - r);
             x &= __builtin_amdgcn_alignbit(next_word32(x), x, s);
@@ -106,7 +108,6 @@ __device__ __forceinline__ uint32_t run_and32(uint32_t x, int &r, int m) {
         }
         return x;
     }
-#endif
     while (r < m) {
         const int s = min(r, m - r);
         uint32_t y = x;
@@ -166,7 +167,10 @@ __device__ __forceinline__ float wave_min_f32(float v) {       // wave-uniform r
     v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));
     v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)));
     v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)));
-    return fminf(fminf(rlf(v, 0), rlf(v, 16)), fminf(rlf(v, 32), rlf(v, 48)));
+    // rows combined as in wave_sum_eval: rows 1, 3 with lane 15 of the row before, rows 2, 3 with lane 31 (the other rows keep v)
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x142, 0xA, 0xF, false)));
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x143, 0xC, 0xF, false)));
+    return rlf(v, 63);
 }
 
 __device__ __forceinline__ int first_set32(uint32_t x) {
@@ -198,6 +202,10 @@ __device__ __forceinline__ void lds_or2_lanes(uint64_t mask, uint32_t addr, uint
 __device__ __forceinline__ void lds_write_lane0(uint32_t addr64, uint64_t v64, uint32_t addr32, uint32_t v32) {
     uint64_t saved;
     asm volatile("s_and_saveexec_b64 %0, 1\n\tds_write_b64 %1, %2\n\tds_write_b32 %3, %4\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "v"(addr64), "v"(v64), "v"(addr32), "v"(v32) : "memory", "scc");
+}
+__device__ __forceinline__ void lds_write_lanes01(uint32_t addr64, uint64_t v64, uint32_t addr32, uint32_t v32) {   // lanes 0 and 1, per-lane operands
+    uint64_t saved;
+    asm volatile("s_and_saveexec_b64 %0, 3\n\tds_write_b64 %1, %2\n\tds_write_b32 %3, %4\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "v"(addr64), "v"(v64), "v"(addr32), "v"(v32) : "memory", "scc");
 }
 __device__ __forceinline__ void lds_write_lane0_b32(uint32_t addr32, uint32_t v32) {
     uint64_t saved;
@@ -277,7 +285,7 @@ __device__ __forceinline__ void fast_refill_trace(const Params &P, int replica, 
     }
 }
 
-template <bool M64, bool REC, int ENT, bool TRACE, int POL = ONGYM_POLICY_FIRST_FIT>
+template <bool M64, bool REC, int ENT, bool TRACE, int POL = ONGYM_POLICY_FIRST_FIT, bool WIDE = true>
 __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step_rec *out, unsigned char *smem) {
     ONGYM_NO_CONTRACT
 #ifdef ONGYM_STAMPS
@@ -415,7 +423,11 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
     float cur_ht = uniform_f32(ge->cur_ht);
     // source | destination << 6, unpacked where a route beyond the first is looked up (9 % of the requests with first fit)
     uint32_t cur_sd = (uint32_t)uniform_i32(ge->cur_src) | ((uint32_t)uniform_i32(ge->cur_dst) << 6);
-    auto pair_base = [&]() -> int { return ((int)(cur_sd & 63u) * N + (int)(cur_sd >> 6)) * K; };      // index of the pair's first route
+    auto pair_base = [&]() -> int {      // index of the pair's first route (behind an optimisation barrier: computed where it is used)
+        uint32_t sd = cur_sd;
+        asm volatile("" : "+s"(sd));
+        return ((int)(sd & 63u) * N + (int)(sd >> 6)) * K;
+    };
     int cur_bi;
     {
         const float br = uniform_f32(ge->cur_br);
@@ -517,7 +529,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         const uint32_t v_rowaddr = occ_base + (uint32_t)lane * (uint32_t)RW * 4u;    // lane l = link l: its bitmap row
         const int len = hi - lo;
 #ifndef ONGYM_X_MARK_LOOP
-        if (len <= 33) {
+        if (!WIDE || len <= 33) {
             const uint64_t m = ((1ull << len) - 1ull) << (lo & 31);
             const uint32_t a = v_rowaddr + (uint32_t)(lo >> 5) * 4u;
             if (free_) lds_or2_lanes(mask, a, (uint32_t)m, (uint32_t)(m >> 32));
@@ -546,6 +558,8 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         }
     };
 
+    int ep_len = P.episode_length;          // held in a scalar register (the lean units are built without loop-invariant code motion)
+    asm volatile("" : "+s"(ep_len));
     const char __attribute__((address_space(1))) *const tab = (const char __attribute__((address_space(1))) *)P.pair_tab2k;
     const char __attribute__((address_space(1))) *const tabp = (const char __attribute__((address_space(1))) *)P.pair_tabp;
 
@@ -654,9 +668,10 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         //   LOWEST_FRAGMENTATION :330-414  routes in order of a fragmentation score that is one number per route (quirk, see
         //                                  ongym_scored.hpp); per route the first start (format high to low, start low to high)
         //                                  whose GSNR passes at slots + 1
-        int ch_k = -1, ch_m = 0, ch_slot = 0, ch_n = 0, ch_path = -1;
-        uint64_t ch_mask = 0;
-        double ch_acc = 0.0, ch_ase = 0.0, ch_nli = 0.0;
+        // (only ch_k is initialised: the others are read when a candidate was chosen, and eight scalar moves per step are saved)
+        int ch_k = -1, ch_m, ch_slot, ch_n, ch_path;
+        uint64_t ch_mask;
+        double ch_acc, ch_ase, ch_nli;
         double best_acc = INFINITY;                 // HIGHEST_SNR: 1/GSNR of the best candidate so far
         bool lf_qot = false;
         // The routes of the request.  FIRST_FIT walks them in order and stops at the first that serves the request; the other
@@ -1011,7 +1026,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                 const int n = (int)rl((uint32_t)t_n, q);
                 const int nn = POL == ONGYM_POLICY_LOWEST_FRAGMENTATION ? n + 1 : n;      // quirk: the request is sized slots + 1 (:357)
                 if (nn + 1 < r_len) { runs = path_and(pmask); r_len = 1; }     // slot counts normally grow as the modulation index falls
-                runs = run_and32(runs, r_len, nn + 1);
+                runs = run_and32<WIDE>(runs, r_len, nn + 1);
                 const int first = first_set32(runs);
                 FSTAMP(2);
                 if (first < 0) continue;
@@ -1063,13 +1078,18 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         if (accepted) {
             // _provision_path (:1288-1325): n slots + one guard slot unless the allocation ends at S
             int end = ch_slot + ch_n; if (end < S) end += 1;
+#ifdef ONGYM_X_ACCEPT_MARKV
+            if (end - ch_slot <= 33) mark_v((uint32_t)ch_mask, M64 ? (uint32_t)(ch_mask >> 32) : 0u, (uint32_t)ch_slot + vz, (uint32_t)(end - ch_slot) + vz, false);
+            else
+#endif
             mark(ch_mask, ch_slot, end, false);
             if (POL == ONGYM_POLICY_LOWEST_FRAGMENTATION) ls_dirty |= ((ch_mask >> lane) & 1ull) != 0;      // these rows changed
             const float rel = v_at + cur_ht;                  // float + float (:1329); compared as float32 (:1114-1115)
             next_rel = fminf(next_rel, rel);
             const uint32_t ra = (uint32_t)ch_mask;
             const uint32_t rb = M64 ? fast_pack_b64(ch_slot, ch_n, ch_m, (uint32_t)(ch_mask >> 32)) : fast_pack_b(ch_slot, ch_n, ch_m, ch_path);
-            lds_write_lane0(rec_base + (uint32_t)active * 8u, (uint64_t)ra | ((uint64_t)rb << 32), rr_base + (uint32_t)active * 4u, __float_as_uint(rel));
+            const uint32_t v_act = vz + (uint32_t)active;        // (address arithmetic on the vector pipe, see vz)
+            lds_write_lane0(rec_base + v_act * 8u, (uint64_t)ra | ((uint64_t)rb << 32), rr_base + v_act * 4u, __float_as_uint(rel));
             active++;
             d_acc++;
             cnt += (lane == 8 + ch_m || lane == 24 + cur_bi) ? 1 : 0;
@@ -1098,7 +1118,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                     const PathRec pr = load_path_rec(path_recs, path);
                     const uint32_t x = path_and(M64 ? ((uint64_t)pr.mask_lo | ((uint64_t)(pr.mask_hi & 0x1FFu) << 32)) : (uint64_t)pr.mask_lo);
                     int r1 = 1;
-                    if (first_set32(run_and32(x, r1, n_small + 1)) >= 0) bosnr = 1;
+                    if (first_set32(run_and32<WIDE>(x, r1, n_small + 1)) >= 0) bosnr = 1;
                 }
                 rflags |= bosnr ? ONGYM_F_BLOCKED_OSNR : ONGYM_F_BLOCKED_RESOURCES;
             } else if (ch_k < 0) {
@@ -1119,11 +1139,11 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                     const PathRec pr = load_path_rec(path_recs, path);
                     const uint32_t x = path_and(M64 ? ((uint64_t)pr.mask_lo | ((uint64_t)(pr.mask_hi & 0x1FFu) << 32)) : (uint64_t)pr.mask_lo);
                     int r1 = 1;
-                    const bool any = first_set32(run_and32(x, r1, n_small + 1)) >= 0;
+                    const bool any = first_set32(run_and32<WIDE>(x, r1, n_small + 1)) >= 0;
                     if (any) { bosnr = 1; bres = 0; }
                     // the LAST pair visited decides blocked_resources: modulation 0's slot count on this path
                     int r2 = 1;
-                    const bool last_has = first_set32(run_and32(x, r2, n_last + 1)) >= 0;
+                    const bool last_has = first_set32(run_and32<WIDE>(x, r2, n_last + 1)) >= 0;
                     bres = last_has ? 0 : 1;
                     (void)n_big;
                 }
@@ -1155,7 +1175,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         }
 
         // the info dict of the terminal step is computed before the next request is drawn (:996-1060)
-        const bool term = (epp + 1 == P.episode_length);
+        const bool term = (epp + 1 == ep_len);
         if (term) {
             if (lane == 0) cold[4] += (osnr_prod != 1.0) ? -10.0 * log10(osnr_prod) : 0.0;      // flush_osnr
             osnr_prod = 1.0;
@@ -1199,7 +1219,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                 const uint2 ab = rec[idx + vz];                             // same address in every lane: broadcast read
                 const uint32_t nk = rec_nm1<M64>(ab.y) + 1u, sk = ((ab.y & 0x7FFu) - nk) >> 1;
                 const uint32_t hi = min(sk + nk + 1u, (uint32_t)S);         // frees n+1 slots, clamped at S (quirk Q7)
-                if (__builtin_amdgcn_readfirstlane(nk) <= 32u)
+                if (!WIDE || __builtin_amdgcn_readfirstlane(nk) <= 32u)
                     mark_v(ab.x, M64 ? (ab.y >> 23) : 0u, sk, hi - sk, true);
                 else {
                     // (unsigned: readfirstlane returns int, and link 31 / link 40 are the sign bits of the two words)
@@ -1210,13 +1230,15 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                 if (POL == ONGYM_POLICY_LOWEST_FRAGMENTATION)          // the departed service's links: their rows changed
                     ls_dirty |= lane < 32 ? ((ab.x >> lane) & 1u) != 0 : (M64 && (((ab.y >> 23) >> (lane - 32)) & 1u) != 0);
                 const int last = active - 1;
-                // move the last record into the hole, neutralise the vacated entry
-                const uint2 lab = rec[last];
-                const float lr = rr[last];
-                if (idx != last) {
-                    lds_write_lane0(rec_base + (uint32_t)idx * 8u, (uint64_t)lab.x | ((uint64_t)lab.y << 32), rr_base + (uint32_t)idx * 4u, __float_as_uint(lr));
-                }
-                lds_write_lane0(rec_base + (uint32_t)last * 8u, 0ull, rr_base + (uint32_t)last * 4u, 0x7F800000u);
+                // lane 0 moves the last record into the hole, lane 1 neutralises the vacated entry (both write the neutral entry when the
+                // hole IS the last record): one masked pair of writes, addresses and data formed on the vector pipe
+                const uint32_t v_last = vz + (uint32_t)last;
+                const uint2 lab = rec[v_last];
+                const float lr = rr[v_last];
+                const bool mv = lane == 0 && idx != last;
+                const uint32_t e = lane == 0 ? (uint32_t)idx + vz : v_last;
+                lds_write_lanes01(rec_base + e * 8u, mv ? ((uint64_t)lab.x | ((uint64_t)lab.y << 32)) : 0ull, rr_base + e * 4u,
+                                  mv ? __float_as_uint(lr) : 0x7F800000u);
                 active = last;
                 wave_sync();
                 FSTAMP(9);
@@ -1243,7 +1265,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             next_rel = wave_min_f32(keep_min);
         }
         d_active_sum += (unsigned long long)active;
-        const bool terminated = epp == P.episode_length;
+        const bool terminated = epp == ep_len;
         if (terminated) d_episodes++;
         if (REC && lane == 0) { recp->active = active; recp->terminated = (uint8_t)terminated; }
         if (terminated && P.auto_reset) {

@@ -681,6 +681,10 @@ static int build(ongym_env *env, const ongym_config *c) {
             if ((rc = upload(env, recs.data(), recs.size(), &d_recs))) return rc;
             P.path_rec = d_recs;
             env->fast_ok = true; env->fast_m64 = m64; env->fast_lds = flds;
+            // every record the lean kernels ever see carries a slot count of the traffic table (records written by the other
+            // entry points included: eligibility demands discrete bit rates): none above 32 -> the narrow build
+            const char *fw = std::getenv("ONGYM_FORCE_WIDE");
+            env->fast_wide = max_n > 32 || (fw && fw[0] == '1');
         }
     }
 
@@ -746,10 +750,10 @@ static int build(ongym_env *env, const ongym_config *c) {
     }
     if (env->fast_ok) {   // the lean kernels of every policy that has one (ongym_fast.hip): LDS limits; a policy whose block
                           // does not fit the CU keeps the generic kernel
-        if (fast_prepare_p0(env)) env->fast_ok = false;
-        env->fast_lb_ok = env->fast_ok && fast_prepare_p1(env) == 0;
-        env->fast_hsnr_ok = env->fast_ok && fast_prepare_p2(env) == 0;
-        env->fast_lf_ok = env->fast_ok && fast_prepare_p10(env) == 0;
+        if (ONGYM_FAST_CALL(fast_prepare, 0, env)) env->fast_ok = false;
+        env->fast_lb_ok = env->fast_ok && ONGYM_FAST_CALL(fast_prepare, 1, env) == 0;
+        env->fast_hsnr_ok = env->fast_ok && ONGYM_FAST_CALL(fast_prepare, 2, env) == 0;
+        env->fast_lf_ok = env->fast_ok && ONGYM_FAST_CALL(fast_prepare, 10, env) == 0;
         env->err.clear();
     }
     // scratch for queries / host-buffer I/O
@@ -860,10 +864,10 @@ int ongym_query_occupancy_policy(ongym_env *env, int32_t policy, int32_t *blocks
     if (lean) {
         int rc;
         switch (policy) {
-            case ONGYM_POLICY_LOAD_BALANCING: rc = fast_occupancy_p1(env, &nb, &lds); break;
-            case ONGYM_POLICY_HIGHEST_SNR: rc = fast_occupancy_p2(env, &nb, &lds); break;
-            case ONGYM_POLICY_LOWEST_FRAGMENTATION: rc = fast_occupancy_p10(env, &nb, &lds); break;
-            default: rc = fast_occupancy_p0(env, &nb, &lds); break;
+            case ONGYM_POLICY_LOAD_BALANCING: rc = ONGYM_FAST_CALL(fast_occupancy, 1, env, &nb, &lds); break;
+            case ONGYM_POLICY_HIGHEST_SNR: rc = ONGYM_FAST_CALL(fast_occupancy, 2, env, &nb, &lds); break;
+            case ONGYM_POLICY_LOWEST_FRAGMENTATION: rc = ONGYM_FAST_CALL(fast_occupancy, 10, env, &nb, &lds); break;
+            default: rc = ONGYM_FAST_CALL(fast_occupancy, 0, env, &nb, &lds); break;
         }
         if (rc) return rc;
         *lds_bytes = lds;
@@ -1019,10 +1023,10 @@ static int launch_run(ongym_env *env, int mode, int policy, int nsteps, const in
         // the lean kernels: same results, half the issued instructions (ongym_fast.hpp)
         int rc;
         switch (policy) {
-            case ONGYM_POLICY_LOAD_BALANCING: rc = fast_launch_p1(env, nsteps, d_out); break;
-            case ONGYM_POLICY_HIGHEST_SNR: rc = fast_launch_p2(env, nsteps, d_out); break;
-            case ONGYM_POLICY_LOWEST_FRAGMENTATION: rc = fast_launch_p10(env, nsteps, d_out); break;
-            default: rc = fast_launch_p0(env, nsteps, d_out); break;
+            case ONGYM_POLICY_LOAD_BALANCING: rc = ONGYM_FAST_CALL(fast_launch, 1, env, nsteps, d_out); break;
+            case ONGYM_POLICY_HIGHEST_SNR: rc = ONGYM_FAST_CALL(fast_launch, 2, env, nsteps, d_out); break;
+            case ONGYM_POLICY_LOWEST_FRAGMENTATION: rc = ONGYM_FAST_CALL(fast_launch, 10, env, nsteps, d_out); break;
+            default: rc = ONGYM_FAST_CALL(fast_launch, 0, env, nsteps, d_out); break;
         }
         if (rc) return rc;
         HIP_TRY(env, hipEventRecord(env->ev1, env->stream));

@@ -477,6 +477,30 @@ def test_sharded_batch_equals_unsharded_bit_exact():
         assert sum(int(e.stats()[f].sum()) for e in parts) == int(st_whole[f].sum())
 
 
+@pytest.mark.parametrize("pid", LEAN_POLICIES)
+def test_narrow_and_wide_lean_builds_agree_bit_exact(pid, monkeypatch):
+    """The lean kernels exist in two builds per policy (csrc/ongym_fast.hip): the narrow one assumes every slot count of the
+    configuration is <= 32 (one-step run-AND shifts, two-word marks, no wide-release path) and is what NSFNET-320 runs; the
+    wide one (ONGYM_FORCE_WIDE=1 selects it for any configuration) is the general code.  Same arithmetic in the same
+    order: step records, statistics and grids must be identical bit for bit.  (The wide build is held to the oracle with
+    slot counts up to 80 by the *_wide_services_* tests, the narrow one by every NSFNET / COST239 / nobel-eu test.)"""
+    tb = golden_tables("nsfnet")
+    B, steps = 256, 1100 if pid in (nat.POLICY_FIRST_FIT, nat.POLICY_LOAD_BALANCING) else 400
+    kw = dict(tables=tb, modulations=jocn_modulations(), num_spectrum_resources=320, capacity=448, load=320,
+              bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), episode_length=1000, batch_size=B)
+    outs = []
+    for wide in (False, True):
+        if wide:
+            monkeypatch.setenv("ONGYM_FORCE_WIDE", "1")       # read at ongym_create
+        e = BatchedQRMSAEnv(**kw); e.seed(11); e.reset()
+        assert e.occupancy(pid)["lean_kernel"]
+        rec = e.step_policy(steps, policy=pid)
+        outs.append((rec.tobytes(), e.stats().tobytes(), [e.grid(r).tobytes() for r in (0, 17, B - 1)]))
+    assert outs[0][0] == outs[1][0], "step records differ between the narrow and the wide build"
+    assert outs[0][1] == outs[1][1], "statistics differ between the narrow and the wide build"
+    assert outs[0][2] == outs[1][2], "grids differ between the narrow and the wide build"
+
+
 def test_device_generator_continuous_bit_rates_vs_oracle():
     """draw_next's randint branch (bit_rate_selection="continuous", qrmsa.pyx:1088-1089) on the DEVICE generator against
     the oracle on the same (seed, replica) streams — slot counts then come from the ceil of get_number_slots

@@ -3,7 +3,7 @@
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 CSRC=$REPO/optical-networking-gym_amd/csrc
 for p in "${@:-0 1 2 10}"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DONGYM_FAST_POLICY=$p $ONGYM_HIP_EXTRA_FLAGS -c -o /dev/null \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DONGYM_FAST_POLICY=$p -DONGYM_FAST_WIDE=${WIDE:-0} ${ONGYM_HIP_EXTRA_FLAGS:--mllvm -disable-machine-licm} -c -o /dev/null \
     -Rpass-analysis=kernel-resource-usage $CSRC/ongym_fast.hip 2>&1 |
   python3 -c '
 import re, sys
