@@ -49,8 +49,11 @@ struct PathRec {
 static_assert(sizeof(PathRec) == 32, "PathRec must be 32 bytes");
 __device__ __forceinline__ PathRec load_path_rec(const __attribute__((address_space(4))) PathRec *t, int path) {
     PathRec r;      // field by field: the constant address space has no copy constructor; still one s_load_dwordx8
-    r.hops = t[path].hops; r.mask_lo = t[path].mask_lo; r.mask_hi = t[path].mask_hi; r.id = t[path].id;
-    r.ase = t[path].ase; r.w1 = t[path].w1;
+    // (an unsigned 32-bit byte offset: base + offset is formed by the scalar load itself, not by a 64-bit add before it)
+    const __attribute__((address_space(4))) PathRec *e =
+        (const __attribute__((address_space(4))) PathRec *)((const __attribute__((address_space(4))) char *)t + ((uint32_t)path << 5));
+    r.hops = e->hops; r.mask_lo = e->mask_lo; r.mask_hi = e->mask_hi; r.id = e->id;
+    r.ase = e->ase; r.w1 = e->w1;
     return r;
 }
 struct TabPair { double x, y; };
@@ -513,10 +516,24 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         uint32_t x = lane < RW ? ~0u : 0u;
         if (M64) {
             uint64_t links = links64;
-            while (links) { const int l = __builtin_ctzll(links); links &= links - 1; x &= occ[l * RW + wl]; }
+            const uint32_t v_word = occ_base + (uint32_t)wl * 4u, v_rw4 = vz + (uint32_t)RW * 4u;
+            while (links) {
+                const int l = __builtin_ctzll(links);
+                asm("s_bitset0_b64 %0, %1" : "+s"(links) : "s"(l));
+                const uint32_t a = __umul24((uint32_t)l, v_rw4) + v_word;
+                x &= *(const __attribute__((address_space(3))) uint32_t *)(uintptr_t)a;
+            }
         } else {
+            // per link: s_ff1, s_bitset0 (one instruction instead of the add/and pair of links &= links - 1), and the row address
+            // lane offset + l * row bytes as one v_mad_u32_u24 on the vector pipe
             uint32_t links = (uint32_t)links64;
-            while (links) { const int l = __builtin_ctz(links); links &= links - 1; x &= occ[l * RW + wl]; }
+            const uint32_t v_word = occ_base + (uint32_t)wl * 4u, v_rw4 = vz + (uint32_t)RW * 4u;
+            while (links) {
+                const int l = __builtin_ctz(links);
+                asm("s_bitset0_b32 %0, %1" : "+s"(links) : "s"(l));
+                const uint32_t a = __umul24((uint32_t)l, v_rw4) + v_word;
+                x &= *(const __attribute__((address_space(3))) uint32_t *)(uintptr_t)a;
+            }
         }
         if (lane == (S >> 5)) x |= 1u << (S & 31);
         return x;
@@ -530,7 +547,8 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         const int len = hi - lo;
 #ifndef ONGYM_X_MARK_LOOP
         if (!WIDE || len <= 33) {
-            const uint64_t m = ((1ull << len) - 1ull) << (lo & 31);
+            uint64_t m;                                      // ((1 << len) - 1) << (lo & 31) is one scalar instruction (len <= 33)
+            asm("s_bfm_b64 %0, %1, %2" : "=s"(m) : "s"(len), "s"(lo & 31));
             const uint32_t a = v_rowaddr + (uint32_t)(lo >> 5) * 4u;
             if (free_) lds_or2_lanes(mask, a, (uint32_t)m, (uint32_t)(m >> 32));
             else lds_and2_lanes(mask, a, ~(uint32_t)m, ~(uint32_t)(m >> 32));
@@ -1021,15 +1039,17 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
 
             while (feas) {
                 const int m = 31 - __builtin_clz(feas);            // best modulation first
-                feas &= ~(1u << m);
+                asm("s_bitset0_b32 %0, %1" : "+s"(feas) : "s"(m));
                 const int q = 8 * cur_bi + m;
                 const int n = (int)rl((uint32_t)t_n, q);
                 const int nn = POL == ONGYM_POLICY_LOWEST_FRAGMENTATION ? n + 1 : n;      // quirk: the request is sized slots + 1 (:357)
                 if (nn + 1 < r_len) { runs = path_and(pmask); r_len = 1; }     // slot counts normally grow as the modulation index falls
                 runs = run_and32<WIDE>(runs, r_len, nn + 1);
-                const int first = first_set32(runs);
+                const uint64_t has = __ballot(runs != 0);
                 FSTAMP(2);
-                if (first < 0) continue;
+                if (!has) continue;
+                const int first_w = __builtin_ctzll(has);
+                const int first = first_w * 32 + __builtin_ctz(rl(runs, first_w));       // == first_set32(runs)
                 if (POL == ONGYM_POLICY_HIGHEST_SNR && !((__ballot(lb < best_acc) >> q) & 1ull)) continue;   // best_acc may have improved
                 if (L < 0) build_cache(pr.mask_lo, pr.mask_hi);
                 FSTAMP(4);
@@ -1214,7 +1234,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         auto depart = [&](int ch, uint64_t bal) {
             while (bal) {
                 const int ln = 63 - __builtin_clzll(bal);                   // highest index first: the hole is filled by a keeper
-                bal &= ~(1ull << ln);
+                asm("s_bitset0_b64 %0, %1" : "+s"(bal) : "s"(ln));
                 const int idx = ch * kWave + ln;
                 const uint2 ab = rec[idx + vz];                             // same address in every lane: broadcast read
                 const uint32_t nk = rec_nm1<M64>(ab.y) + 1u, sk = ((ab.y & 0x7FFu) - nk) >> 1;
