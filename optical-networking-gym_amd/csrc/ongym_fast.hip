@@ -5,6 +5,8 @@
 // for its policy; ongym_hip.hip dispatches on the policy id.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "ongym_host.hpp"
 #include "ongym_fast.hpp"
 
@@ -95,9 +97,16 @@ int FAST_FN(fast_prepare)(ongym_env *env) {
 int FAST_FN(fast_launch)(ongym_env *env, int nsteps, ongym_step_rec *d_out) {
     const bool tr = env->P.req_mode == kReqTrace;
     const size_t lds = lds_of(env);
+    // the kernel sums the running services of its steps in 32 bits (one scalar add per step): a launch is split so that
+    // steps x capacity stays below 2^32
+    const long long chunk = std::max(1LL, 0xFFFFFFFFLL / std::max(1, env->P.capacity));
     return with_kernel(env, d_out != nullptr, tr, [&](auto kernel) -> int {
-        hipLaunchKernelGGL(kernel, dim3(env->P.batch), dim3(64), lds, env->stream, env->d_P, nsteps, d_out);
-        HIP_TRY(env, hipGetLastError());
+        for (long long done = 0; done < nsteps; done += chunk) {
+            const int n = (int)std::min<long long>(chunk, nsteps - done);
+            hipLaunchKernelGGL(kernel, dim3(env->P.batch), dim3(64), lds, env->stream, env->d_P, n,
+                               d_out ? d_out + (size_t)done * env->P.batch : nullptr);
+            HIP_TRY(env, hipGetLastError());
+        }
         return 0;
     });
 }

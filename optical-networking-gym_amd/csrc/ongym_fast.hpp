@@ -269,7 +269,7 @@ __device__ __forceinline__ void fast_refill(const Params &P, const DevEnv *ge, u
     int bi = 0;
     for (int i = 0; i < nb - 1; i++) bi += (G(P.bit_rate_cum)[i] <= xb) ? 1 : 0;
     const int p0 = G(P.pair_paths)[(src * N + dst) * K];
-    rq_pk = (uint32_t)src | ((uint32_t)dst << 6) | ((uint32_t)bi << 12) | ((uint32_t)(p0 + 1) << 15);
+    rq_pk = (uint32_t)src | ((uint32_t)dst << 6) | ((uint32_t)bi << 12) | ((uint32_t)p0 << 15);
 }
 
 // The same ring from a replayed trace (ongym_set_requests with bit rates of the configured table, checked on the host):
@@ -284,7 +284,7 @@ __device__ __forceinline__ void fast_refill_trace(const Params &P, int replica, 
         int bi = 0;
         for (int b = 0; b < P.n_bit_rates; b++) if ((float)G(P.bit_rates)[b] == q.bit_rate) bi = b;
         const int p0 = G(P.pair_paths)[((int)q.source * P.n_nodes + (int)q.destination) * P.k_paths];
-        rq_pk = (uint32_t)q.source | ((uint32_t)q.destination << 6) | ((uint32_t)bi << 12) | ((uint32_t)(p0 + 1) << 15);
+        rq_pk = (uint32_t)q.source | ((uint32_t)q.destination << 6) | ((uint32_t)bi << 12) | ((uint32_t)p0 << 15);
     }
 }
 
@@ -388,6 +388,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             t1_lim_hi = usable1 ? lim * (1.0 + 1e-9) : -1.0;
         }
     }
+    const uint32_t t_pk = t_n >= 1 ? (uint32_t)t_n | ((uint32_t)(lane & 7) << 11) | ((uint32_t)(t_n - 1) << 14) : 0u;
     // the tables the policy's search uses
     constexpr bool kLF = POL == ONGYM_POLICY_LOWEST_FRAGMENTATION;
     const int &w_n = kLF ? t1_n : t_n;
@@ -440,8 +441,11 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
     int cur_p0 = uniform_i32(KC(P.pair_paths)[pair_base()]);
     const __attribute__((address_space(4))) PathRec *const path_recs = KC(reinterpret_cast<const PathRec *>(P.path_rec));
     // launch deltas
-    int d_pops = 0, d_acc = 0, d_steps = 0, d_evals = 0, d_skips = 0, d_paths = 0, d_hops = 0, d_flags = 0, d_episodes = 0;
-    unsigned long long d_active_sum = 0;
+    // (not counted per step: requests popped = the advance of the request index; steps = the advance of the step loop, except for a
+    //  replayed trace, whose exhausted steps do not count; modulations settled by the bound = M x routes examined - d_feas with first fit)
+    int d_acc = 0, d_steps = 0, d_evals = 0, d_skips = 0, d_feas = 0, d_paths = 0, d_hops = 0, d_flags = 0, d_episodes = 0;
+    int it = 0, it_base = 0;                // step loop counter; steps before it_base are already in DevEnv
+    uint32_t d_active_sum = 0;              // < 2^32: the host splits a launch so that steps x capacity stays below (fast_launch)
 
     float rq_iat, rq_ht;
     uint32_t rq_pk;
@@ -456,7 +460,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
     wave_sync();
 
     // ---- fold the launch state into DevEnv (memory); idempotent: deltas are zeroed once added ----
-    auto store_env = [&]() {
+    auto store_env = [&](int it_upto) {
         int terms = lane_terms;
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) terms += __shfl_xor(terms, m);
@@ -467,11 +471,13 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         for (int i = 0; i < 8; i++) { hist[i] = (int)rl((uint32_t)cnt, 8 + i); nreq_b[i] = (int)rl((uint32_t)cnt, 16 + i); nacc_b[i] = (int)rl((uint32_t)cnt, 24 + i); brs[i] = i < P.n_bit_rates ? (float)KC(P.bit_rates)[i] : 0.f; }
         if (lane == 0) {
             ongym_stats &s = ge->st;
-            ge->req_index = req_base + (uint64_t)rq_pos;
+            const uint64_t req_now = req_base + (uint64_t)rq_pos;
+            s.services_processed += (long long)(req_now - ge->req_index);
+            ge->req_index = req_now;
             s.current_time = (double)v_at;
             ge->cur_at = v_at; ge->cur_ht = cur_ht; ge->cur_br = brs[cur_bi]; ge->cur_src = (int)(cur_sd & 63u); ge->cur_dst = (int)(cur_sd >> 6);
             ge->cur_id = epp - 1; ge->have_request = have ? 1 : 0;
-            s.services_processed += d_pops; s.episode_services_processed = epp;
+            s.episode_services_processed = epp;
             s.services_accepted += d_acc; s.total_accepted += d_acc;
             s.rejected = erej;
             double rq = 0.0, pv = 0.0;       // exact: bit rates are integer-valued (eligibility), counts are small integers
@@ -483,13 +489,16 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             s.episode_osnr_sum = cold[4] + (osnr_prod != 1.0 ? -10.0 * log10(osnr_prod) : 0.0);
             ge->osnr_flushed = cold[4]; ge->osnr_prod = osnr_prod;
             s.episodes_completed += d_episodes;
-            s.total_steps += d_steps; s.total_gn_evals += d_evals; s.total_gn_shortcuts += d_skips;
+            s.total_steps += TRACE ? d_steps : it_upto - it_base;
+            s.total_gn_evals += d_evals;
+            s.total_gn_shortcuts += POL == ONGYM_POLICY_FIRST_FIT ? M * d_paths - d_feas : d_skips;
             s.total_interferer_terms += terms; s.total_paths_tried += d_paths; s.total_path_hops += d_hops;
             s.total_active_sum += (long long)d_active_sum;
             s.active = active; s.flags |= d_flags;
         }
-        d_pops = d_acc = d_steps = d_evals = d_skips = d_paths = d_hops = d_flags = d_episodes = 0;
+        d_acc = d_steps = d_evals = d_skips = d_feas = d_paths = d_hops = d_flags = d_episodes = 0;
         d_active_sum = 0;
+        it_base = it_upto;
     };
 
     // next request: pop the ring, advance the float32 clock (envs/qrmsa.pyx:1079-1111)
@@ -504,8 +513,8 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         else v_at = v_at + rlf(rq_iat, rq_pos);         // at = float32(current_time + expovariate)
         cur_ht = rlf(rq_ht, rq_pos);
         rq_pos++;
-        cur_sd = pk & 0xFFFu; cur_bi = (pk >> 12) & 7; cur_p0 = (int)(pk >> 15) - 1;
-        epp++; d_pops++;
+        cur_sd = pk & 0xFFFu; cur_bi = (pk >> 12) & 7; cur_p0 = (int)pk >> 15;            // the first route's id, sign-extended (-1: the pair has no route)
+        epp++;
         cnt += (lane == 16 + cur_bi) ? 1 : 0;           // bit_rate_requested, by bit rate
     };
 
@@ -669,7 +678,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         next_rel = wave_min_f32(m);
     }
     FSTAMP(11);
-    for (int it = 0; it < nsteps; ++it) {
+    for (it = 0; it < nsteps; ++it) {
         if (TRACE && !have) {           // no request source left: the step is a no-op (as in k_run)
             if (REC && lane == 0) {
                 ongym_step_rec r;
@@ -781,7 +790,8 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             uint32_t feas = (uint32_t)(__ballot(lb < w_lim_hi) >> (8 * cur_bi)) & 0xFFu;
             // HIGHEST_SNR: nor can a format beat the best candidate so far when its bound is not below that one's 1/GSNR
             if (POL == ONGYM_POLICY_HIGHEST_SNR) feas &= (uint32_t)(__ballot(lb < best_acc) >> (8 * cur_bi));
-            d_skips += M - __popc(feas);            // modulations settled by the bound (statistics only)
+            if (POL == ONGYM_POLICY_FIRST_FIT) d_feas += __popc(feas);      // modulations settled by the bound (statistics only): see store_env
+            else d_skips += M - __popc(feas);
             FSTAMP(0);
             if (!feas) continue;
             const uint64_t pmask = mask_of(pr);
@@ -1107,7 +1117,10 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             const float rel = v_at + cur_ht;                  // float + float (:1329); compared as float32 (:1114-1115)
             next_rel = fminf(next_rel, rel);
             const uint32_t ra = (uint32_t)ch_mask;
-            const uint32_t rb = M64 ? fast_pack_b64(ch_slot, ch_n, ch_m, (uint32_t)(ch_mask >> 32)) : fast_pack_b(ch_slot, ch_n, ch_m, ch_path);
+            // record word b (fast_pack_b / fast_pack_b64): the format's part (n | modulation << 11 | (n - 1) << 14) comes from the
+            // per-lane table, the rest is the start and the path id (or the mask's high bits); ch_n == t_n of the chosen lane
+            const uint32_t rb = rl(t_pk, 8 * cur_bi + ch_m) + 2u * (uint32_t)ch_slot +
+                                ((M64 ? (uint32_t)(ch_mask >> 32) : (uint32_t)(ch_path & 0x1FF)) << 23);
             const uint32_t v_act = vz + (uint32_t)active;        // (address arithmetic on the vector pipe, see vz)
             lds_write_lane0(rec_base + v_act * 8u, (uint64_t)ra | ((uint64_t)rb << 32), rr_base + v_act * 4u, __float_as_uint(rel));
             active++;
@@ -1170,7 +1183,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                 rflags |= (bres ? ONGYM_F_BLOCKED_RESOURCES : 0) | (bosnr ? ONGYM_F_BLOCKED_OSNR : 0);
             }
         }
-        d_steps++;
+        if (TRACE) d_steps++;
         FSTAMP(6);
 
         ongym_step_rec *const recp = REC ? out + (size_t)it * P.batch + replica : nullptr;
@@ -1200,7 +1213,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             if (lane == 0) cold[4] += (osnr_prod != 1.0) ? -10.0 * log10(osnr_prod) : 0.0;      // flush_osnr
             osnr_prod = 1.0;
             wave_sync();
-            store_env();
+            store_env(it + 1);
             __threadfence_block();
             if (lane == 0) {
                 const ongym_stats &s = ge->st;
@@ -1284,7 +1297,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         }
             next_rel = wave_min_f32(keep_min);
         }
-        d_active_sum += (unsigned long long)active;
+        d_active_sum += (uint32_t)active;
         const bool terminated = epp == ep_len;
         if (terminated) d_episodes++;
         if (REC && lane == 0) { recp->active = active; recp->terminated = (uint8_t)terminated; }
@@ -1305,7 +1318,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
     }
 
     // ---- store: DevEnv, bitmap, records (lean codec -> generic codec) ----
-    store_env();
+    store_env(nsteps);
     wave_sync();
     {
         uint32_t *g = reinterpret_cast<uint32_t *>(P.occ + (size_t)replica * E * P.row_words);
