@@ -202,13 +202,14 @@ __device__ __forceinline__ void lds_or2_lanes(uint64_t mask, uint32_t addr, uint
     uint64_t saved;
     asm volatile("s_and_saveexec_b64 %0, %1\n\tds_or_b32 %2, %3\n\tds_or_b32 %2, %4 offset:4\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "s"(mask), "v"(addr), "v"(v0), "v"(v1) : "memory", "scc");
 }
-__device__ __forceinline__ void lds_write_lane0(uint32_t addr64, uint64_t v64, uint32_t addr32, uint32_t v32) {
+// (the 8-byte record as two dwords: ds_write2_b32 takes them from two VGPRs, no 64-bit value has to be assembled first)
+__device__ __forceinline__ void lds_write_lane0(uint32_t addr64, uint32_t lo, uint32_t hi, uint32_t addr32, uint32_t v32) {
     uint64_t saved;
-    asm volatile("s_and_saveexec_b64 %0, 1\n\tds_write_b64 %1, %2\n\tds_write_b32 %3, %4\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "v"(addr64), "v"(v64), "v"(addr32), "v"(v32) : "memory", "scc");
+    asm volatile("s_and_saveexec_b64 %0, 1\n\tds_write2_b32 %1, %2, %3 offset1:1\n\tds_write_b32 %4, %5\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "v"(addr64), "v"(lo), "v"(hi), "v"(addr32), "v"(v32) : "memory", "scc");
 }
-__device__ __forceinline__ void lds_write_lanes01(uint32_t addr64, uint64_t v64, uint32_t addr32, uint32_t v32) {   // lanes 0 and 1, per-lane operands
+__device__ __forceinline__ void lds_write_lanes01(uint32_t addr64, uint32_t lo, uint32_t hi, uint32_t addr32, uint32_t v32) {   // lanes 0 and 1, per-lane operands
     uint64_t saved;
-    asm volatile("s_and_saveexec_b64 %0, 3\n\tds_write_b64 %1, %2\n\tds_write_b32 %3, %4\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "v"(addr64), "v"(v64), "v"(addr32), "v"(v32) : "memory", "scc");
+    asm volatile("s_and_saveexec_b64 %0, 3\n\tds_write2_b32 %1, %2, %3 offset1:1\n\tds_write_b32 %4, %5\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "v"(addr64), "v"(lo), "v"(hi), "v"(addr32), "v"(v32) : "memory", "scc");
 }
 __device__ __forceinline__ void lds_write_lane0_b32(uint32_t addr32, uint32_t v32) {
     uint64_t saved;
@@ -443,7 +444,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
     // launch deltas
     // (not counted per step: requests popped = the advance of the request index; steps = the advance of the step loop, except for a
     //  replayed trace, whose exhausted steps do not count; modulations settled by the bound = M x routes examined - d_feas with first fit)
-    int d_acc = 0, d_steps = 0, d_evals = 0, d_skips = 0, d_feas = 0, d_paths = 0, d_hops = 0, d_flags = 0, d_episodes = 0;
+    int d_acc = 0, d_rej = 0, d_steps = 0, d_evals = 0, d_skips = 0, d_feas = 0, d_paths = 0, d_hops = 0, d_flags = 0, d_episodes = 0;
     int it = 0, it_base = 0;                // step loop counter; steps before it_base are already in DevEnv
     uint32_t d_active_sum = 0;              // < 2^32: the host splits a launch so that steps x capacity stays below (fast_launch)
 
@@ -478,7 +479,8 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             ge->cur_at = v_at; ge->cur_ht = cur_ht; ge->cur_br = brs[cur_bi]; ge->cur_src = (int)(cur_sd & 63u); ge->cur_dst = (int)(cur_sd >> 6);
             ge->cur_id = epp - 1; ge->have_request = have ? 1 : 0;
             s.episode_services_processed = epp;
-            s.services_accepted += d_acc; s.total_accepted += d_acc;
+            const int acc_ = TRACE ? d_acc : it_upto - it_base - d_rej;     // every step of the device generator accepts or rejects
+            s.services_accepted += acc_; s.total_accepted += acc_;
             s.rejected = erej;
             double rq = 0.0, pv = 0.0;       // exact: bit rates are integer-valued (eligibility), counts are small integers
             int eacc = 0;
@@ -496,7 +498,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             s.total_active_sum += (long long)d_active_sum;
             s.active = active; s.flags |= d_flags;
         }
-        d_acc = d_steps = d_evals = d_skips = d_feas = d_paths = d_hops = d_flags = d_episodes = 0;
+        d_acc = d_rej = d_steps = d_evals = d_skips = d_feas = d_paths = d_hops = d_flags = d_episodes = 0;
         d_active_sum = 0;
         it_base = it_upto;
     };
@@ -1122,14 +1124,14 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
             const uint32_t rb = rl(t_pk, 8 * cur_bi + ch_m) + 2u * (uint32_t)ch_slot +
                                 ((M64 ? (uint32_t)(ch_mask >> 32) : (uint32_t)(ch_path & 0x1FF)) << 23);
             const uint32_t v_act = vz + (uint32_t)active;        // (address arithmetic on the vector pipe, see vz)
-            lds_write_lane0(rec_base + v_act * 8u, (uint64_t)ra | ((uint64_t)rb << 32), rr_base + v_act * 4u, __float_as_uint(rel));
+            lds_write_lane0(rec_base + v_act * 8u, ra, rb, rr_base + v_act * 4u, __float_as_uint(rel));
             active++;
-            d_acc++;
+            if (TRACE) d_acc++;
             cnt += (lane == 8 + ch_m || lane == 24 + cur_bi) ? 1 : 0;
             osnr_prod *= ch_acc;
             if (osnr_prod < 1e-250) { if (lane == 0) cold[4] += -10.0 * log10(osnr_prod); osnr_prod = 1.0; wave_sync(); }
         } else {
-            erej++;
+            erej++; d_rej++;
             if (ch_k < 0 && POL == ONGYM_POLICY_LOWEST_FRAGMENTATION && lf_qot) {
                 rflags |= ONGYM_F_QOT_ERROR | ONGYM_F_BLOCKED_OSNR;
             } else if (ch_k < 0 && POL != ONGYM_POLICY_FIRST_FIT) {
@@ -1270,8 +1272,7 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
                 const float lr = rr[v_last];
                 const bool mv = lane == 0 && idx != last;
                 const uint32_t e = lane == 0 ? (uint32_t)idx + vz : v_last;
-                lds_write_lanes01(rec_base + e * 8u, mv ? ((uint64_t)lab.x | ((uint64_t)lab.y << 32)) : 0ull, rr_base + e * 4u,
-                                  mv ? __float_as_uint(lr) : 0x7F800000u);
+                lds_write_lanes01(rec_base + e * 8u, mv ? lab.x : 0u, mv ? lab.y : 0u, rr_base + e * 4u, mv ? __float_as_uint(lr) : 0x7F800000u);
                 active = last;
                 wave_sync();
                 FSTAMP(9);
