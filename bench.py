@@ -81,7 +81,7 @@ def algorithmic_bytes_per_step(stats_sum, S):
 
 
 def kernel_source_hash():
-    """sha256 over the kernel sources (csrc/*.hip, csrc/*.hpp, include/*.h, sorted by name): tools/pmc_summarise.py stores
+    """sha256 over the kernel sources (csrc/*.hip, csrc/*.hpp, include/*.h, sorted by name) and the build flags: tools/pmc_summarise.py stores
     it with every counter summary, bench.py compares it with the sources it runs and marks a summary of other sources stale."""
     import glob
     import hashlib
@@ -92,6 +92,8 @@ def kernel_source_hash():
         h.update(os.path.basename(f).encode() + b"\0")
         with open(f, "rb") as fh:
             h.update(fh.read())
+    import __graft_entry__ as ge       # ... and the compiler flags of the build recipe (the lean units are built without machine LICM)
+    h.update(" ".join(ge.HIP_FLAGS + ge.FAST_UNIT_FLAGS).encode())
     return h.hexdigest()[:16]
 
 

@@ -2,7 +2,7 @@
 """Soak: many replicas x thousands of steps (several episodes) per case with launch power -8..+8 dBm, load 100..1000 Erlang and
 margins 0..3 dB spread over the replicas; every replica's final grid, clocks and counters against the CPU oracle (OpenMP over
 replicas).  Cases: first fit on NSFNET / COST239 / nobel-eu, and the lean kernels of load balancing, highest SNR and lowest
-fragmentation.  Last run: profiles/r03_soak_vs_oracle.txt.   python tools/soak_vs_oracle.py [case indices]   (repository root, GPU)"""
+fragmentation.  Last run: profiles/r03_soak_vs_oracle.txt.   python tools/soak_vs_oracle.py [--narrow] [case indices]   (repository root, GPU)"""
 import sys, os, time
 sys.path[:0] = ["tests", "optical-networking-gym_amd"]
 import numpy as np
@@ -20,18 +20,23 @@ CASES = [("nsfnet", 320, 0, 1024, 8000), ("cost239", 320, 0, 1024, 8000), ("nobe
          # the M64 instantiations of the policy kernels (41 links) and COST239
          ("nobel-eu", 320, 1, 512, 3000), ("nobel-eu", 160, 2, 96, 1200), ("nobel-eu", 160, 10, 96, 1200),
          ("cost239", 160, 2, 96, 1200), ("cost239", 160, 10, 96, 1200)]
-if len(sys.argv) > 1:
-    CASES = [CASES[int(a)] for a in sys.argv[1:]]
+# --narrow: bit rates (10, 40, 100, 400) only, i.e. every slot count <= 32: the NARROW builds of the lean kernels (the ones the
+# BASELINE workloads run); default: 1 Tb/s services of up to 80 slots included -> the wide builds
+NARROW = "--narrow" in sys.argv
+BIT_RATES = (10, 40, 100, 400) if NARROW else (10, 40, 100, 400, 1000)
+args = [a for a in sys.argv[1:] if a != "--narrow"]
+if args:
+    CASES = [CASES[int(a)] for a in args]
 threads = len(os.sched_getaffinity(0))
 for topo, S, pid, B, steps in CASES:
     loads = rng.uniform(100, 1000, B) * S / 320; lps = rng.uniform(-8.0, 8.0, B); margins = rng.choice([0.0, 0.5, 1.5, 3.0], B)
     kw = dict(modulations=jocn_modulations(), num_spectrum_resources=S, batch=B, capacity=1024, episode_length=1000,
-              auto_reset=True, load=300, bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400, 1000),
+              auto_reset=True, load=300, bit_rate_selection="discrete", bit_rates=BIT_RATES,
               replica_load=loads, replica_launch_power_dbm=lps, replica_margin=margins)
     holder = nat.ConfigHolder(golden_tables(topo), **kw)
     env = BatchedQRMSAEnv(tables=golden_tables(topo), modulations=jocn_modulations(), batch_size=B, num_spectrum_resources=S,
                           capacity=1024, episode_length=1000, auto_reset=True, load=300, bit_rate_selection="discrete",
-                          bit_rates=(10, 40, 100, 400, 1000), replica_load=loads, replica_launch_power_dbm=lps,
+                          bit_rates=BIT_RATES, replica_load=loads, replica_launch_power_dbm=lps,
                           replica_margin=margins)
     env.seed(2025); env.reset()
     assert env.occupancy(pid)["lean_kernel"]
@@ -52,5 +57,5 @@ for topo, S, pid, B, steps in CASES:
                                              "last_episode_accepted", "total_paths_tried" if pid == 0 else "episode_services_accepted")) \
             and np.array_equal(env.grid(r), o.grid())
         bad += (not ok)
-    print(f"{topo} S={S} policy {pid}: replicas differing: {bad} of {B} after {steps} steps each ({B * steps / 1e6:.1f} M requests) | "
+    print(f"{'narrow' if NARROW else 'wide'} build, {topo} S={S} policy {pid}: replicas differing: {bad} of {B} after {steps} steps each ({B * steps / 1e6:.1f} M requests) | "
           f"oracle time {time.time() - t0:.1f} s on {threads} threads", flush=True)
