@@ -315,6 +315,14 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     a.i[1] = __builtin_amdgcn_readlane(a.i[1], lane);
     return a.d;
 }
+// x as an opaque value: the operation that produced it cannot be fused with the one that consumes it.  HIP compiles device code
+// with -ffp-contract=fast and __dmul_rn / __dadd_rn are plain operators there, so `a * b + c` written with them still becomes ONE
+// fma — one rounding where the reference (Python floats) makes two.  Found by the round-3 soak: two routes whose lowest-
+// fragmentation scores tie with two roundings (the lower index wins, heuristics.py:404-406) and differ by an ulp with one.
+__device__ __forceinline__ double fp_barrier(double x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
 // Wave-wide fp64 sum, identical bits in every lane: symmetric DPP exchanges inside each row of 16 lanes
 // (quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror, row_mirror), then the 4 row sums through v_readlane.
 __device__ __forceinline__ double wave_sum(double v) {

@@ -1,4 +1,4 @@
-// ongym_fast.hpp — the lean fused policy + step kernels (k_fast<M64, REC, ENT, WAVES, TRACE, POL>): same path and same results
+// ongym_fast.hpp — the lean fused policy + step kernels (k_fast<M64, REC, ENT, WAVES, TRACE, POL, WIDE>): same path and same results
 // as the generic k_run, built around ISSUE-SLOT economy.  tools/ubench/issue_rates.hip measured on MI355X (cycles per
 // wave-instruction per SIMD, >= 2 waves): 32-bit VALU 2.5, fp64 / 64-bit shift / DPP mov / v_readlane / v_alignbit 4.2,
 // SALU 4.3, ds_read_b32 ~9.  The round-1 kernel spent 726 VALU + 625 SALU per request; at 5 waves/SIMD both pipes were
@@ -25,6 +25,13 @@
 //   * policies that look at every route fetch the routes' ids and records together (lane k = k-th route) and examine the
 //     routes in the order that makes the FIRST route that serves the request the answer (ascending load / score);
 //     policies that evaluate many starts of a (route, format) put the candidates on the lanes (eval_cands).
+//   * WIDE = false (the narrow units, chosen on the host when no slot count of the traffic table exceeds 32): a run-AND step is
+//     one shift of 1..31 bits, a mark touches two words, and the > 32-slot release path does not exist.
+//   * the units are compiled with -mllvm -disable-machine-licm (__graft_entry__.FAST_UNIT_FLAGS): hoisting the constants of cold
+//     code out of the step loop cost 53 spilled SGPRs + 13 spilled VGPRs; and wave-uniform values that must stay in a scalar
+//     register across the loop are pinned by hand (ep_len).  Round 3 measured that this kernel pays per ISSUED INSTRUCTION
+//     (~0.3 % per scalar instruction on the per-request path) and not per hidden latency: hence s_bitset0 / s_bfm_b64 /
+//     v_mad_u32_u24 / ds_write2_b32 in place of the generic sequences, counters derived at store time, and vz.
 // The state in HBM is the generic kernels' (same arrays, same record codec), converted on load / store: every other entry
 // point keeps working on the same environment, and a launch may be split anywhere.
 //
@@ -657,7 +664,9 @@ __device__ __forceinline__ void fast_run(const Params &P, int nsteps, ongym_step
         const bool in = (pmask >> lane) & 1ull;
         const int tc = wave_sum_i32(in ? ls_cuts : 0), tsl = wave_sum_i32(in ? ls_sl : 0), tsq = wave_sum_i32(in ? ls_sq : 0);
         const double rss = tsl == 0 ? 0.0 : sqrt((double)tsq) / (double)tsl;
-        return uniform_f64(__dadd_rn(__dadd_rn(__dmul_rn(0.33, se), __dmul_rn(0.33, (double)tc)), __dmul_rn(0.34, rss)));
+        // every product and sum rounded on its own (fp_barrier: no fma), as Python computes 0.33 * se + 0.33 * cuts + 0.34 * rss
+        const double t1 = fp_barrier(0.33 * se), t2 = fp_barrier(0.33 * (double)tc), t3 = fp_barrier(0.34 * rss);
+        return uniform_f64(fp_barrier(t1 + t2) + t3);
     };
 
     if (!uniform_i32(ge->have_request)) {            // never reset: every step is a no-op (same as k_run)

@@ -74,7 +74,9 @@ __device__ __forceinline__ double lf_route_score(const Ctx &c, const PathRef &p)
     for (int mm = 32; mm >= 1; mm >>= 1) tc += __shfl_xor(tc, mm);
     const double tsq = wave_sum(sq), tsl = wave_sum(sl);   // integers < 2^53: exact in any order
     const double rss = tsl == 0.0 ? 0.0 : sqrt(tsq) / tsl;
-    const double score = __dadd_rn(__dadd_rn(__dmul_rn(0.33, se), __dmul_rn(0.33, (double)uniform_i32(tc))), __dmul_rn(0.34, rss));
+    // 0.33 * se + 0.33 * cuts + 0.34 * rss with every product and sum rounded on its own (fp_barrier: no fma)
+    const double t1 = fp_barrier(0.33 * se), t2 = fp_barrier(0.33 * (double)uniform_i32(tc)), t3 = fp_barrier(0.34 * rss);
+    const double score = fp_barrier(t1 + t2) + t3;
     return uniform_f64(score);
 }
 

@@ -501,6 +501,55 @@ def test_narrow_and_wide_lean_builds_agree_bit_exact(pid, monkeypatch):
     assert outs[0][2] == outs[1][2], "grids differ between the narrow and the wide build"
 
 
+@pytest.mark.parametrize("generic", [False, True], ids=["lean", "generic"])
+def test_lowest_fragmentation_score_tie_keeps_the_lower_route(generic, monkeypatch):
+    """Found by the round-3 soak (COST239, S = 160, lowest fragmentation, replica 54 of the case, request 618): routes 2 and 4 of
+    the request have mean link entropies one ulp apart and equal cuts / rss, so 0.33 * se + 0.33 * cuts + 0.34 * rss TIES when every
+    product and sum is rounded on its own (Python floats: heuristics.py:375-384, the lower route index keeps the lead, :404-406) and
+    differs by an ulp when `0.33 * se + 0.33 * cuts` is one fma - which is what HIP's default -ffp-contract=fast made of it in
+    both kernels (__dmul_rn / __dadd_rn are plain operators).  The oracle (volatile temporaries) was right; the kernels now
+    round like it (fp_barrier).  The same stream and parameters, both kernels, against the oracle to the end of the episode."""
+    if generic:
+        monkeypatch.setenv("ONGYM_FORCE_GENERIC", "1")
+    B, r, steps = 55, 54, 700
+    loads = np.full(B, 74.35965007739468); lps = np.full(B, -0.41180015260154335); margins = np.zeros(B)
+    kw = dict(modulations=jocn_modulations(), num_spectrum_resources=160, capacity=1024, episode_length=1000, auto_reset=True,
+              load=300, bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400, 1000), replica_load=loads,
+              replica_launch_power_dbm=lps, replica_margin=margins)
+    tb = golden_tables("cost239")
+    env = BatchedQRMSAEnv(tables=tb, batch_size=B, **kw); env.seed(2025); env.reset()
+    assert env.occupancy(nat.POLICY_LOWEST_FRAGMENTATION)["lean_kernel"] == (not generic)
+    got = env.step_policy(steps, policy=nat.POLICY_LOWEST_FRAGMENTATION)[:, r]
+    o = OracleEnv(nat.ConfigHolder(tb, batch=B, **kw), replica=r); o.seed(2025); o.reset()
+    want = o.run_policy(nat.POLICY_LOWEST_FRAGMENTATION, steps)
+    assert (int(want["route"][618]), int(want["modulation"][618]), int(want["slot"][618])) == (2, 4, 69)    # the tie: route 2, not 4
+    assert_records_equal(got, want, "lowest-fragmentation score tie")
+    np.testing.assert_array_equal(env.grid(r), o.grid())
+
+
+def test_lean_launch_longer_than_the_32_bit_sum_allows_is_split_on_the_host():
+    """The lean kernels add up the running services of their steps in 32 bits; `fast_launch` (csrc/ongym_fast.hip) therefore
+    splits a launch so that steps x capacity stays below 2^32.  With capacity 8192 the limit is 524 287 steps: one call of
+    524 287 + 60 steps (two launches, the step records of the second one written behind the first one's) must equal the same
+    steps made in two calls, bit for bit."""
+    tb = golden_tables("nsfnet")
+    cap = 8192
+    chunk = 0xFFFFFFFF // cap
+    kw = dict(tables=tb, modulations=jocn_modulations(), num_spectrum_resources=320, capacity=cap, load=300,
+              bit_rate_selection="discrete", bit_rates=(10, 40, 100, 400), episode_length=1000, batch_size=2)
+    a = BatchedQRMSAEnv(**kw); a.seed(3); a.reset()
+    assert a.occupancy()["lean_kernel"]
+    rec_a = a.step_policy(chunk + 60)
+    b = BatchedQRMSAEnv(**kw); b.seed(3); b.reset()
+    b.step_policy(chunk, record=False)
+    rec_b = b.step_policy(60)
+    assert rec_a[chunk:].tobytes() == rec_b.tobytes()
+    assert a.stats().tobytes() == b.stats().tobytes()
+    st = a.stats()
+    assert int(st["total_steps"][0]) == chunk + 60 and int(st["services_processed"][0]) >= chunk + 60
+    assert 100 * (chunk + 60) < int(st["total_active_sum"][0]) < 400 * (chunk + 60)       # ~ 210-290 running services per step
+
+
 def test_device_generator_continuous_bit_rates_vs_oracle():
     """draw_next's randint branch (bit_rate_selection="continuous", qrmsa.pyx:1088-1089) on the DEVICE generator against
     the oracle on the same (seed, replica) streams — slot counts then come from the ceil of get_number_slots
