@@ -2,7 +2,7 @@
 """Soak: many replicas x thousands of steps (several episodes) per case with launch power -8..+8 dBm, load 100..1000 Erlang and
 margins 0..3 dB spread over the replicas; every replica's final grid, clocks and counters against the CPU oracle (OpenMP over
 replicas).  Cases: first fit on NSFNET / COST239 / nobel-eu, and the lean kernels of load balancing, highest SNR and lowest
-fragmentation.  Last run: profiles/r03_soak_vs_oracle.txt.   python tools/soak_vs_oracle.py [--narrow] [case indices]   (repository root, GPU)"""
+fragmentation.  Last run: profiles/r03_soak_vs_oracle.txt.   python tools/soak_vs_oracle.py [--narrow] [--seed N] [case indices]   (repository root, GPU)"""
 import sys, os, time
 sys.path[:0] = ["tests", "optical-networking-gym_amd"]
 import numpy as np
@@ -11,7 +11,6 @@ from oracle_lib import OracleEnv, batch_run_first_fit
 from optical_networking_gym import _native as nat
 from optical_networking_gym.envs.batched import BatchedQRMSAEnv
 from oracle_lib import batch_run_policy
-rng = np.random.default_rng(7)
 # (topology, slots, policy id, replicas, steps): first fit on three topologies (nobel-eu: the M64 record codec), then the lean
 # kernels of the other three JOCN heuristics (the oracle's highest SNR / lowest fragmentation run at tens of steps per second
 # per core: smaller samples)
@@ -24,7 +23,11 @@ CASES = [("nsfnet", 320, 0, 1024, 8000), ("cost239", 320, 0, 1024, 8000), ("nobe
 # BASELINE workloads run); default: 1 Tb/s services of up to 80 slots included -> the wide builds
 NARROW = "--narrow" in sys.argv
 BIT_RATES = (10, 40, 100, 400) if NARROW else (10, 40, 100, 400, 1000)
+SEED = 7                                  # --seed N: other per-replica loads / launch powers / margins (and another traffic seed)
 args = [a for a in sys.argv[1:] if a != "--narrow"]
+if "--seed" in args:
+    i = args.index("--seed"); SEED = int(args[i + 1]); del args[i:i + 2]
+rng = np.random.default_rng(SEED)
 if args:
     CASES = [CASES[int(a)] for a in args]
 threads = len(os.sched_getaffinity(0))
@@ -38,7 +41,7 @@ for topo, S, pid, B, steps in CASES:
                           capacity=1024, episode_length=1000, auto_reset=True, load=300, bit_rate_selection="discrete",
                           bit_rates=BIT_RATES, replica_load=loads, replica_launch_power_dbm=lps,
                           replica_margin=margins)
-    env.seed(2025); env.reset()
+    env.seed(2018 + SEED); env.reset()
     assert env.occupancy(pid)["lean_kernel"]
     done = 0
     while done < steps:
@@ -48,7 +51,7 @@ for topo, S, pid, B, steps in CASES:
     t0 = time.time()
     oracles = []
     for r in range(B):
-        o = OracleEnv(holder, replica=r); o.seed(2025); o.reset(); oracles.append(o)
+        o = OracleEnv(holder, replica=r); o.seed(2018 + SEED); o.reset(); oracles.append(o)
     assert batch_run_policy(oracles, pid, steps, threads) == B * steps
     bad = 0
     for r, o in enumerate(oracles):
@@ -57,5 +60,5 @@ for topo, S, pid, B, steps in CASES:
                                              "last_episode_accepted", "total_paths_tried" if pid == 0 else "episode_services_accepted")) \
             and np.array_equal(env.grid(r), o.grid())
         bad += (not ok)
-    print(f"{'narrow' if NARROW else 'wide'} build, {topo} S={S} policy {pid}: replicas differing: {bad} of {B} after {steps} steps each ({B * steps / 1e6:.1f} M requests) | "
+    print(f"{'narrow' if NARROW else 'wide'} build, seed {SEED}, {topo} S={S} policy {pid}: replicas differing: {bad} of {B} after {steps} steps each ({B * steps / 1e6:.1f} M requests) | "
           f"oracle time {time.time() - t0:.1f} s on {threads} threads", flush=True)
